@@ -1,0 +1,198 @@
+/*
+ * pann.h -- C-ABI of the MI355X-native graph-ANN hot path (beam search, robustPrune,
+ * batched / all-pairs distances) that replaces, for this path only, ParlayANN's
+ *
+ *   algorithms/utils/beamSearch.h:22-214   filtered_beam_search           -> pann_batch_search*
+ *   algorithms/utils/beamSearch.h:353-387  searchAll   (parallel_for seam) -> pann_batch_search*
+ *   algorithms/utils/beamSearch.h:537-565  qsearchAll  (parallel_for seam) -> pann_batch_search*
+ *   algorithms/utils/beamSearch.h:499-521  beam_search_rerank__ (build)    -> pann_batch_search* with
+ *                                          query_ids != NULL and a visited-list output
+ *   algorithms/utils/euclidian_point.h:54-90, mips_point.h:43-65           -> device distance functors
+ *   algorithms/vamana/index.h:63-137       knn_index::robustPrune          -> pann_robust_prune_batch
+ *   algorithms/vamana/index.h:247-266      batch_insert step 1 (search+prune per inserted point)
+ *                                                                          -> pann_insert_batch
+ *   algorithms/HCNNG/hcnng_index.h:145-181 MSTk all-pairs + per-row 10-NN  -> pann_leaf_knn
+ *   data_tools/compute_groundtruth.cpp:22-59 brute-force kNN               -> pann_bruteforce_knn
+ *
+ * The reference has no FFI of its own for this path (it is a header-only template library); these
+ * entry points are what a cgo/ctypes/pybind binding placed at the parallel_for seams above would
+ * bind.  INTEGRATION.md shows the reference-side stubs.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types.
+ *   - every function returns an int status (PANN_OK == 0); pann_last_error() gives the text for the
+ *     calling thread.  The reference prints and abort()s (beamSearch.h:38-41,368-372); host wrappers
+ *     reproduce that on a non-zero status.
+ *   - "host" entry points take host pointers and stage through the handle's device buffers;
+ *     "_dev" entry points take device pointers (HIP) and a hipStream_t passed as void*, perform no
+ *     allocation and no synchronisation, and are what bench.py times.
+ *   - graph rows on the HOST side use the reference layout (graph.h:134-141,234-242):
+ *     n x (max_deg+1) uint32, slot 0 = degree.  The device mirror is private to the handle.
+ */
+#ifndef PANN_H_
+#define PANN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PANN_ABI_VERSION 1
+
+/* status codes */
+#define PANN_OK 0
+#define PANN_ERR_BAD_ARG 1
+#define PANN_ERR_HIP 2
+#define PANN_ERR_NO_DEVICE 3
+#define PANN_ERR_UNSUPPORTED 4
+#define PANN_ERR_OVERFLOW 5 /* a per-query device buffer (visited list) was too small */
+
+/* element type of the stored vectors (reference: Euclidian_Point<T>/Mips_Point<T>, T in
+ * {uint8_t,int8_t,float}; PANN_F16 is this build's extension) */
+typedef enum { PANN_U8 = 0, PANN_I8 = 1, PANN_F32 = 2, PANN_F16 = 3 } pann_dtype;
+
+/* distance functor: euclidian_point.h:54-90 / mips_point.h:43-65 */
+typedef enum { PANN_L2 = 0, PANN_MIPS = 1 } pann_metric;
+
+/* field-for-field mirror of QueryParams (algorithms/utils/types.h:218-231) */
+typedef struct pann_query_params {
+  int64_t k;            /* QueryParams::k            (0 during build: no cut-prune) */
+  int64_t beam;         /* QueryParams::beamSize */
+  double cut;           /* QueryParams::cut */
+  int64_t limit;        /* QueryParams::limit        (max number of visited vertices) */
+  int64_t degree_limit; /* QueryParams::degree_limit */
+  int32_t rerank_factor;/* QueryParams::rerank_factor (used by the rerank wrapper only) */
+  float pad;            /* QueryParams::pad */
+} pann_query_params;
+
+/* Outputs of one batched search.  Any pointer may be NULL (that output is skipped).
+ * ids/dists rows hold the first min(out_k, frontier size) entries of the final frontier, sorted
+ * by (dist, id) (beamSearch.h:46-48,211); unused slots are 0xFFFFFFFF / +inf.
+ * visited_ids/visited_dists hold the visited list (beamSearch.h:112-113) in VISIT order, at most
+ * visited_cap entries per query (the reference keeps it sorted by (dist,id); callers that need
+ * that order sort the row, robustPrune sorts its candidates anyway, vamana/index.h:83). */
+typedef struct pann_search_out {
+  uint32_t* ids;           /* nq x out_k */
+  float* dists;            /* nq x out_k */
+  uint32_t out_k;
+  uint32_t* frontier_size; /* nq */
+  uint32_t* visited_count; /* nq : visitedElts.size()  (stats.h:70-73 increment_visited) */
+  uint32_t* dist_cmps;     /* nq : full_dist_cmps      (beamSearch.h:213) */
+  uint32_t* degree_sum;    /* nq : sum over visited v of min(deg(v), degree_limit) -- roofline numerator */
+  uint32_t* visited_ids;   /* nq x visited_cap */
+  float* visited_dists;    /* nq x visited_cap */
+  uint32_t visited_cap;
+} pann_search_out;
+
+typedef struct pann_index pann_index;
+
+/* ---- library ------------------------------------------------------------------------------- */
+int pann_abi_version(void);
+const char* pann_last_error(void);
+int pann_device_count(void);
+
+/* ---- index handle: device mirror of PointRange (point_range.h:42-141) + Graph (graph.h:125-250) */
+
+/* points: host slab, n rows of d elements, row stride row_stride_bytes (PointRange::aligned_bytes,
+ * point_range.h:94).  graph: host n x (max_deg+1) uint32 in the reference layout, or NULL for an
+ * empty graph (all degrees 0, as Graph(maxDeg,n) gives, graph.h:145-147). */
+int pann_index_create(pann_index** out, const void* points, uint64_t n, uint32_t d, int dtype,
+                      uint64_t row_stride_bytes, int metric, const uint32_t* graph,
+                      uint32_t max_deg, int device);
+void pann_index_destroy(pann_index* idx);
+
+uint64_t pann_index_size(const pann_index* idx);
+uint32_t pann_index_dims(const pann_index* idx);
+uint32_t pann_index_max_degree(const pann_index* idx);
+int pann_index_device(const pann_index* idx);
+
+/* Replace the whole graph from a host n x (max_deg+1) slab. */
+int pann_index_set_graph(pann_index* idx, const uint32_t* graph);
+/* Replace m rows: rows is m x (max_deg+1) in the reference layout (edgeRange::update_neighbors,
+ * graph.h:84-99).  Must not overlap a search on the same handle (vamana/index.h:247-270). */
+int pann_index_update_rows(pann_index* idx, const uint32_t* row_ids, const uint32_t* rows,
+                           uint64_t m);
+/* Copy the device graph back to a host n x (max_deg+1) slab. */
+int pann_index_get_graph(pann_index* idx, uint32_t* graph_out);
+
+/* ---- batched beam search (beamSearch.h:22-214 run for nq queries at once) -------------------- */
+
+/* queries: nq rows of d elements of the index dtype, row stride q_stride_bytes; OR query_ids:
+ * nq base-point ids (the query is Points[id] and neighbours equal to id are skipped, the
+ * `Points[a].same_as(p)` test of beamSearch.h:133).  Exactly one of the two is non-NULL.
+ * starts: nstarts start vertices shared by all queries (all in-scope drivers pass {0}:
+ * vamana/index.h:148, check_nn_recall.h:178). */
+int pann_batch_search(pann_index* idx, const void* queries, const uint32_t* query_ids, uint64_t nq,
+                      uint64_t q_stride_bytes, const uint32_t* starts, uint32_t nstarts,
+                      const pann_query_params* qp, const pann_search_out* out);
+
+/* Same, all pointers are device pointers; launched on `stream` (hipStream_t); no sync, no alloc
+ * except growth of the handle's private workspace on first use (call once to warm up). */
+int pann_batch_search_dev(pann_index* idx, const void* d_queries, const uint32_t* d_query_ids,
+                          uint64_t nq, uint64_t q_stride_bytes, const uint32_t* d_starts,
+                          uint32_t nstarts, const pann_query_params* qp,
+                          const pann_search_out* d_out, void* stream);
+
+/* ---- distances ------------------------------------------------------------------------------ */
+
+/* out[i] = distance(Points[a_ids[i]], Points[b_ids[i]]), i < m  (Point::distance). host pointers */
+int pann_pair_distances(pann_index* idx, const uint32_t* a_ids, const uint32_t* b_ids, uint64_t m,
+                        float* out);
+/* out[q*m + j] = distance(query q, Points[ids[j]])  for nq external queries. host pointers */
+int pann_query_distances(pann_index* idx, const void* queries, uint64_t nq, uint64_t q_stride_bytes,
+                         const uint32_t* ids, uint64_t m, float* out);
+
+/* ---- robustPrune (vamana/index.h:63-137) ---------------------------------------------------- */
+
+/* For each of m owners p_i: candidates = given list (ids, and dists to p_i; if cand_dists is NULL
+ * they are computed as in the id-only overload :124-137) plus, when add_out_nbrs != 0, p_i's current
+ * out-neighbours (:72-77); sort by (dist,id), unique by id, greedy alpha-prune to at most R.
+ * cand_offsets has m+1 entries (CSR).  out_rows is m x (R+1) in the reference row layout
+ * (slot 0 = count).  out_dist_cmps (optional) gets distance_comps per owner.  Host pointers. */
+int pann_robust_prune_batch(pann_index* idx, const uint32_t* owners, uint64_t m,
+                            const uint32_t* cand_ids, const float* cand_dists,
+                            const uint64_t* cand_offsets, double alpha, uint32_t R,
+                            int add_out_nbrs, uint32_t* out_rows, uint32_t* out_dist_cmps);
+
+/* ---- Vamana batch_insert (vamana/index.h:188-316) ------------------------------------------- */
+
+typedef struct pann_build_stats {
+  double t_search_s, t_prune_s, t_bidirect_s, t_reprune_s; /* the reference's three phase timers, :217-222 */
+  uint64_t search_dist_cmps, prune_dist_cmps, visited_total;
+} pann_build_stats;
+
+/* One batch: for every id in batch_ids (m of them) beam-search from `start` with
+ * QueryParams(0, L, 0.0, n, max_deg) (:250), robustPrune the visited list (:264), write the rows
+ * (:268-270), then add the reverse edges: append-without-repeats when the row stays within R,
+ * otherwise re-prune (:278-300).  The graph inside the handle is updated in place. */
+int pann_vamana_insert_batch(pann_index* idx, const uint32_t* batch_ids, uint64_t m, uint32_t start,
+                             uint32_t R, uint32_t L, double alpha, pann_build_stats* stats);
+
+/* Whole build_index (vamana/index.h:150-186): num_passes passes of prefix-doubling batches over a
+ * seeded random permutation (this build's own permutation), alpha = 1.0 on all but
+ * the last pass, optional final neighbour sort by distance. */
+int pann_vamana_build(pann_index* idx, uint32_t R, uint32_t L, double alpha, int num_passes,
+                      uint64_t seed, int sort_neighbors, pann_build_stats* stats);
+
+/* ---- dense all-pairs: HCNNG leaf (hcnng_index.h:145-181) and ground truth ------------------- */
+
+/* For one leaf given by N ids: for each i the m smallest (dist,id) neighbours among the other
+ * leaf members.  out_ids/out_dists are N x m (row i sorted ascending).  Host pointers. */
+int pann_leaf_knn(pann_index* idx, const uint32_t* ids, uint32_t N, uint32_t m, uint32_t* out_ids,
+                  float* out_dists);
+/* Many leaves in one call: leaf_offsets has nleaves+1 entries into ids; outputs are
+ * (total ids) x m. */
+int pann_leaf_knn_batch(pann_index* idx, const uint32_t* ids, const uint64_t* leaf_offsets,
+                        uint64_t nleaves, uint32_t m, uint32_t* out_ids, float* out_dists);
+
+/* Brute-force k nearest base points for nq external queries (compute_groundtruth.cpp:22-59):
+ * out rows sorted by (dist,id). Host pointers. */
+int pann_bruteforce_knn(pann_index* idx, const void* queries, uint64_t nq, uint64_t q_stride_bytes,
+                        uint32_t k, uint32_t* out_ids, float* out_dists);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PANN_H_ */

@@ -1,0 +1,562 @@
+// pann_oracle.cpp -- CPU restatement of ParlayANN's beam-search / robustPrune / batch_insert /
+// HCNNG-leaf path.  TEST INFRASTRUCTURE ONLY: only tests/, __graft_entry__.smoke() and the
+// cpu_baseline leg of bench.py may load this library; the product (parlayann_amd, libpann.so)
+// never links, loads or calls it.
+//
+// PARITY UNPINNED: the reference ships no golden vectors, known-answer tests or fixtures for this
+// path (its only tests are placeholders, algorithms/vamana/index_test.cc:1-5), and the reference
+// itself cannot be built here: every header includes parlaylib, an un-vendored dependency
+// (empty submodule, .gitmodules:1-3; CMakeLists.txt:14-22 fetches GIT_TAG master).  This file is
+// therefore a restatement written from reading the reference sources, each function citing the
+// file:line it follows; the one third-party function that influences search results,
+// parlay::hash64_2 (called at beamSearch.h:55), is restated from parlaylib's published
+// include/parlay/utilities.h (splitmix64 finaliser) and isolated in hash64_2() below.
+//
+// Plain C++17, no dependencies; threads over queries with std::thread exactly where the reference
+// has parlay::parallel_for (beamSearch.h:374,556; vamana/index.h:247,268,289).
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <thread>
+#include <utility>
+#include <vector>
+#include <chrono>
+
+namespace {
+
+enum { DT_U8 = 0, DT_I8 = 1, DT_F32 = 2, DT_F16 = 3 };
+enum { M_L2 = 0, M_MIPS = 1 };
+
+// parlaylib include/parlay/utilities.h hash64_2 (used at beamSearch.h:55)
+inline uint64_t hash64_2(uint64_t x) {
+  x = (x ^ (x >> 30)) * UINT64_C(0xbf58476d1ce4e5b9);
+  x = (x ^ (x >> 27)) * UINT64_C(0x94d049bb133111eb);
+  x = x ^ (x >> 31);
+  return x;
+}
+
+// IEEE binary16 -> binary32, exact (the F16 extension stores halves; arithmetic is in f32)
+inline float half_to_float(uint16_t h) {
+  uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  uint32_t exp = (h >> 10) & 0x1f;
+  uint32_t man = h & 0x3ffu;
+  uint32_t bits;
+  if (exp == 0) {
+    if (man == 0) {
+      bits = sign;
+    } else {  // subnormal
+      int e = -1;
+      do { e++; man <<= 1; } while ((man & 0x400u) == 0);
+      man &= 0x3ffu;
+      bits = sign | ((uint32_t)(127 - 15 - e) << 23) | (man << 13);
+    }
+  } else if (exp == 31) {
+    bits = sign | 0x7f800000u | (man << 13);
+  } else {
+    bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
+  }
+  float f;
+  std::memcpy(&f, &bits, 4);
+  return f;
+}
+
+// euclidian_point.h:54-62 (u8), :74-81 (i8), :83-90 (f32); mips_point.h:43-65.
+// Integer types accumulate in int32 and cast once; float accumulates strictly left to right with
+// one rounding per multiply and per add (this file is compiled with -ffp-contract=off).
+float distance(int dtype, int metric, const void* pa, const void* pb, unsigned d) {
+  if (dtype == DT_U8) {
+    const uint8_t* p = (const uint8_t*)pa; const uint8_t* q = (const uint8_t*)pb;
+    int32_t r = 0;
+    if (metric == M_L2) {
+      for (unsigned i = 0; i < d; i++) { int32_t t = (int32_t)p[i] - (int32_t)q[i]; r += t * t; }
+      return (float)r;
+    }
+    for (unsigned i = 0; i < d; i++) r += (int32_t)p[i] * (int32_t)q[i];
+    return -((float)r);
+  }
+  if (dtype == DT_I8) {
+    const int8_t* p = (const int8_t*)pa; const int8_t* q = (const int8_t*)pb;
+    int32_t r = 0;
+    if (metric == M_L2) {
+      for (unsigned i = 0; i < d; i++) { int32_t t = (int32_t)q[i] - (int32_t)p[i]; r += t * t; }
+      return (float)r;
+    }
+    for (unsigned i = 0; i < d; i++) r += (int32_t)q[i] * (int32_t)p[i];
+    return -((float)r);
+  }
+  if (dtype == DT_F32) {
+    const float* p = (const float*)pa; const float* q = (const float*)pb;
+    float r = 0.0f;
+    if (metric == M_L2) {
+      for (unsigned i = 0; i < d; i++) { float t = q[i] - p[i]; r += t * t; }
+      return r;
+    }
+    for (unsigned i = 0; i < d; i++) r += q[i] * p[i];
+    return -r;
+  }
+  // DT_F16: convert, then the f32 rule
+  const uint16_t* p = (const uint16_t*)pa; const uint16_t* q = (const uint16_t*)pb;
+  float r = 0.0f;
+  if (metric == M_L2) {
+    for (unsigned i = 0; i < d; i++) { float t = half_to_float(q[i]) - half_to_float(p[i]); r += t * t; }
+    return r;
+  }
+  for (unsigned i = 0; i < d; i++) r += half_to_float(q[i]) * half_to_float(p[i]);
+  return -r;
+}
+
+struct IdDist { uint32_t id; float dist; };
+// total order used everywhere: beamSearch.h:46-48, vamana/index.h:80-82
+inline bool less_id_dist(const IdDist& a, const IdDist& b) {
+  return a.dist < b.dist || (a.dist == b.dist && a.id < b.id);
+}
+
+struct Dataset {
+  const uint8_t* points; uint64_t n; uint32_t d; int dtype; uint64_t stride; int metric;
+  const uint32_t* graph; uint32_t maxdeg;  // reference layout: n x (maxdeg+1), slot 0 = degree
+  const void* row(uint64_t i) const { return points + i * stride; }
+  const uint32_t* grow(uint64_t i) const { return graph + i * (uint64_t)(maxdeg + 1); }
+  float dist(const void* q, uint32_t i) const { return distance(dtype, metric, row(i), q, d); }
+  float dist_ids(uint32_t a, uint32_t b) const { return distance(dtype, metric, row(a), row(b), d); }
+};
+
+struct SearchParams { int64_t k, beam; double cut; int64_t limit, degree_limit; };
+
+struct SearchResult {
+  std::vector<IdDist> frontier;  // sorted by (dist,id), <= beam
+  std::vector<IdDist> visited;   // sorted by (dist,id) (beamSearch.h:112-113)
+  std::vector<IdDist> visit_order;  // same elements, in the order they were visited
+  uint64_t dist_cmps = 0;        // full_dist_cmps (beamSearch.h:213); == dist_cmps without filtering
+  uint64_t degree_sum = 0;       // sum of min(deg, degree_limit) over visited (roofline numerator)
+};
+
+// beamSearch.h:22-214 with use_filtering == false (the only mode reachable for the in-scope
+// configurations).  self_id >= 0 reproduces Points[a].same_as(p)
+// (:133) for build-time searches where p is a base point.
+void beam_search(const Dataset& D, const void* q, int64_t self_id, const uint32_t* starts,
+                 uint32_t nstarts, const SearchParams& QP, SearchResult& R) {
+  const int beam = (int)QP.beam;
+  // :52-59 lossy direct-mapped filter
+  int bits = std::max<int>(10, (int)std::ceil(std::log2((double)beam * (double)beam)) - 2);
+  std::vector<uint32_t> table((size_t)1 << bits, 0xFFFFFFFFu);
+  const uint64_t mask = ((uint64_t)1 << bits) - 1;
+  auto seen = [&](uint32_t a) -> bool {
+    size_t loc = (size_t)(hash64_2((uint64_t)a) & mask);
+    if (table[loc] == a) return true;
+    table[loc] = a;
+    return false;
+  };
+
+  std::vector<IdDist>& frontier = R.frontier;
+  frontier.clear(); R.visited.clear(); R.visit_order.clear(); R.degree_sum = 0;
+  frontier.reserve(beam);
+  for (uint32_t s = 0; s < nstarts; s++) {  // :66-70
+    frontier.push_back(IdDist{starts[s], D.dist(q, starts[s])});
+    seen(starts[s]);
+  }
+  std::sort(frontier.begin(), frontier.end(), less_id_dist);
+
+  std::vector<IdDist> unvisited(std::max<size_t>(beam, nstarts));  // :74-76
+  for (size_t i = 0; i < frontier.size(); i++) unvisited[i] = frontier[i];
+
+  std::vector<IdDist>& visited = R.visited;
+  uint64_t dist_cmps = nstarts;  // :83-84
+  int remain = (int)frontier.size();
+  int64_t num_visited = 0;
+  std::vector<IdDist> merged(2 * std::max<size_t>(beam, nstarts) + D.maxdeg);  // :89-90
+  std::vector<IdDist> cand;
+  std::vector<uint32_t> keep;
+  int offset = 0;
+  const float big = (float)std::numeric_limits<int>::max();  // :152
+
+  while (remain > offset && num_visited < QP.limit) {  // :107
+    IdDist cur = unvisited[offset];
+    visited.insert(std::upper_bound(visited.begin(), visited.end(), cur, less_id_dist), cur);
+    R.visit_order.push_back(cur);
+    num_visited++;
+    bool full = (int)frontier.size() == beam;  // :115
+
+    keep.clear();
+    const uint32_t* row = D.grow(cur.id);
+    int64_t ne = std::min<int64_t>((int64_t)row[0], QP.degree_limit);  // :130
+    R.degree_sum += (uint64_t)std::max<int64_t>(ne, 0);
+    for (int64_t i = 0; i < ne; i++) {
+      uint32_t a = row[1 + i];
+      if (seen(a) || (int64_t)a == self_id) continue;  // :133 (filter is updated before same_as)
+      keep.push_back(a);
+    }
+    dist_cmps += keep.size();  // :137 (and :155: one full distance per survivor)
+
+    float cutoff = full ? frontier.back().dist : big;  // :150-152
+    for (uint32_t a : keep) {
+      float dist = D.dist(q, a);
+      if (dist >= cutoff) continue;  // :157
+      cand.push_back(IdDist{a, dist});
+    }
+    // :162-168 -- note: candidates persist across skipped iterations
+    if (cand.empty() ||
+        (QP.limit >= 2 * (int64_t)beam && (int64_t)cand.size() < beam / 8 && offset + 1 < remain)) {
+      offset++;
+      continue;
+    }
+    offset = 0;
+
+    std::sort(cand.begin(), cand.end(), less_id_dist);  // :173
+    auto cend = std::unique(cand.begin(), cand.end(),
+                            [](const IdDist& a, const IdDist& b) { return a.id == b.id; });
+    size_t msize = std::set_union(frontier.begin(), frontier.end(), cand.begin(), cend,
+                                  merged.begin(), less_id_dist) - merged.begin();  // :178-181
+    cand.clear();
+    msize = std::min<size_t>((size_t)beam, msize);  // :185
+
+    if (QP.k > 0 && (int64_t)msize > QP.k && D.metric == M_L2) {  // :190 (is_metric(): L2 only)
+      // :191-195: the bound is pair{0, cut * merged[k].dist}; the product is formed in double and
+      // narrowed to float when the pair is converted to (indexType, float) for `less`.
+      IdDist thr{0u, (float)(QP.cut * (double)merged[QP.k].dist)};
+      size_t ub = std::upper_bound(merged.begin(), merged.begin() + msize, thr, less_id_dist) -
+                  merged.begin();
+      msize = std::max<size_t>(ub, frontier.size());
+    }
+    frontier.assign(merged.begin(), merged.begin() + msize);  // :198-200
+
+    remain = (int)(std::set_difference(frontier.begin(),
+                                       frontier.begin() + std::min<size_t>(frontier.size(), beam),
+                                       visited.begin(), visited.end(), unvisited.begin(),
+                                       less_id_dist) - unvisited.begin());  // :203-208
+  }
+  R.dist_cmps = dist_cmps;
+}
+
+// vamana/index.h:63-120.  cand: (id, dist to p).  Returns new neighbours, adds to *dcmps.
+void robust_prune(const Dataset& D, uint32_t p, std::vector<IdDist>& cand, double alpha, uint32_t R,
+                  bool add, std::vector<uint32_t>& out, uint64_t* dcmps) {
+  uint64_t dc = 0;
+  if (add) {  // :72-77
+    const uint32_t* row = D.grow(p);
+    for (uint32_t i = 0; i < row[0]; i++) {
+      dc++;
+      cand.push_back(IdDist{row[1 + i], D.dist_ids(row[1 + i], p)});
+    }
+  }
+  std::sort(cand.begin(), cand.end(), less_id_dist);  // :83
+  cand.erase(std::unique(cand.begin(), cand.end(),
+                         [](const IdDist& a, const IdDist& b) { return a.id == b.id; }),
+             cand.end());  // :86-88
+  out.clear();
+  size_t idx = 0;
+  const uint32_t DEAD = 0xFFFFFFFFu;  // the reference's -1 sentinel (:99,112)
+  while (out.size() < R && idx < cand.size()) {  // :95
+    uint32_t ps = cand[idx].id;
+    idx++;
+    if (ps == p || ps == DEAD) continue;
+    out.push_back(ps);
+    for (size_t i = idx; i < cand.size(); i++) {  // :105-115
+      uint32_t pp = cand[i].id;
+      if (pp != DEAD) {
+        dc++;
+        float d_sp = D.dist_ids(ps, pp);
+        float d_pp = cand[i].dist;
+        if (alpha * (double)d_sp <= (double)d_pp) cand[i].id = DEAD;  // :111, in double
+      }
+    }
+  }
+  if (dcmps) *dcmps += dc;
+}
+
+template <typename F>
+void parallel_for(size_t lo, size_t hi, int nthreads, F f) {
+  if (nthreads <= 1 || hi - lo < 2) { for (size_t i = lo; i < hi; i++) f(i); return; }
+  std::atomic<size_t> next(lo);
+  const size_t chunk = std::max<size_t>(1, (hi - lo) / ((size_t)nthreads * 16));
+  std::vector<std::thread> ts;
+  for (int t = 0; t < nthreads; t++)
+    ts.emplace_back([&]() {
+      for (;;) {
+        size_t b = next.fetch_add(chunk);
+        if (b >= hi) break;
+        size_t e = std::min(hi, b + chunk);
+        for (size_t i = b; i < e; i++) f(i);
+      }
+    });
+  for (auto& t : ts) t.join();
+}
+
+inline uint64_t splitmix64(uint64_t& s) {
+  uint64_t z = (s += UINT64_C(0x9e3779b97f4a7c15));
+  z = (z ^ (z >> 30)) * UINT64_C(0xbf58476d1ce4e5b9);
+  z = (z ^ (z >> 27)) * UINT64_C(0x94d049bb133111eb);
+  return z ^ (z >> 31);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pann_oracle_hw_threads(void) { return (int)std::thread::hardware_concurrency(); }
+
+uint64_t pann_oracle_hash64_2(uint64_t x) { return hash64_2(x); }
+
+float pann_oracle_distance(int dtype, int metric, const void* a, const void* b, uint32_t d) {
+  return distance(dtype, metric, a, b, d);
+}
+
+// Batched beam search = searchAll / qsearchAll (beamSearch.h:353-387,537-565): one task per query.
+// queries: nq rows (stride q_stride) or query_ids (base points; self excluded).  Outputs as in
+// pann_search_out, except that visited lists are returned SORTED by (dist,id) (reference order)
+// in visited_* and in visit order in visit_order_* (either may be NULL).
+int pann_oracle_batch_search(const void* points, uint64_t n, uint32_t d, int dtype, uint64_t stride,
+                             int metric, const uint32_t* graph, uint32_t maxdeg,
+                             const void* queries, const uint32_t* query_ids, uint64_t nq,
+                             uint64_t q_stride, const uint32_t* starts, uint32_t nstarts,
+                             int64_t k, int64_t beam, double cut, int64_t limit,
+                             int64_t degree_limit, uint32_t out_k, uint32_t* out_ids,
+                             float* out_dists, uint32_t* frontier_size, uint32_t* visited_count,
+                             uint32_t* dist_cmps, uint32_t* degree_sum, uint32_t visited_cap,
+                             uint32_t* visited_ids, float* visited_dists,
+                             uint32_t* visit_order_ids, int nthreads) {
+  if (nstarts == 0 || beam <= 0 || nstarts > (uint32_t)beam) return 1;
+  Dataset D{(const uint8_t*)points, n, d, dtype, stride, metric, graph, maxdeg};
+  SearchParams QP{k, beam, cut, limit, degree_limit};
+  std::atomic<int> overflow(0);
+  parallel_for(0, nq, nthreads, [&](size_t i) {
+    SearchResult R;
+    const void* q = query_ids ? D.row(query_ids[i]) : (const void*)((const uint8_t*)queries + i * q_stride);
+    beam_search(D, q, query_ids ? (int64_t)query_ids[i] : -1, starts, nstarts, QP, R);
+    for (uint32_t j = 0; j < out_k; j++) {
+      bool ok = j < R.frontier.size();
+      if (out_ids) out_ids[i * out_k + j] = ok ? R.frontier[j].id : 0xFFFFFFFFu;
+      if (out_dists) out_dists[i * out_k + j] = ok ? R.frontier[j].dist : std::numeric_limits<float>::infinity();
+    }
+    if (frontier_size) frontier_size[i] = (uint32_t)R.frontier.size();
+    if (visited_count) visited_count[i] = (uint32_t)R.visited.size();
+    if (dist_cmps) dist_cmps[i] = (uint32_t)R.dist_cmps;
+    if (degree_sum) degree_sum[i] = (uint32_t)R.degree_sum;
+    if (visited_cap) {
+      if (R.visited.size() > visited_cap) overflow = 1;
+      size_t m = std::min<size_t>(R.visited.size(), visited_cap);
+      for (size_t j = 0; j < m; j++) {
+        if (visited_ids) visited_ids[i * visited_cap + j] = R.visited[j].id;
+        if (visited_dists) visited_dists[i * visited_cap + j] = R.visited[j].dist;
+        if (visit_order_ids) visit_order_ids[i * visited_cap + j] = R.visit_order[j].id;
+      }
+    }
+  });
+  return overflow ? 5 : 0;
+}
+
+// Batched robustPrune; same contract as pann_robust_prune_batch (include/pann.h).
+int pann_oracle_robust_prune_batch(const void* points, uint64_t n, uint32_t d, int dtype,
+                                   uint64_t stride, int metric, const uint32_t* graph,
+                                   uint32_t maxdeg, const uint32_t* owners, uint64_t m,
+                                   const uint32_t* cand_ids, const float* cand_dists,
+                                   const uint64_t* cand_offsets, double alpha, uint32_t R,
+                                   int add_out_nbrs, uint32_t* out_rows, uint32_t* out_dist_cmps,
+                                   int nthreads) {
+  Dataset D{(const uint8_t*)points, n, d, dtype, stride, metric, graph, maxdeg};
+  parallel_for(0, m, nthreads, [&](size_t i) {
+    std::vector<IdDist> cand;
+    uint64_t dc = 0;
+    for (uint64_t j = cand_offsets[i]; j < cand_offsets[i + 1]; j++) {
+      if (cand_dists) cand.push_back(IdDist{cand_ids[j], cand_dists[j]});
+      else { dc++; cand.push_back(IdDist{cand_ids[j], D.dist_ids(cand_ids[j], owners[i])}); }  // :131-134
+    }
+    std::vector<uint32_t> out;
+    robust_prune(D, owners[i], cand, alpha, R, add_out_nbrs != 0, out, &dc);
+    uint32_t* row = out_rows + i * (uint64_t)(R + 1);
+    row[0] = (uint32_t)out.size();
+    for (uint32_t j = 0; j < R; j++) row[1 + j] = j < out.size() ? out[j] : 0;
+    if (out_dist_cmps) out_dist_cmps[i] = (uint32_t)dc;
+  });
+  return 0;
+}
+
+// The insertion order used by this build (oracle and product alike; DESIGN.md "build determinism"):
+// Fisher-Yates driven by splitmix64(seed).  parlay::random_permutation (vamana/index.h:212) is not
+// reproducible without parlaylib, so graph identity with upstream is out of reach by construction.
+void pann_oracle_permutation(uint64_t m, uint64_t seed, uint32_t* out) {
+  for (uint64_t i = 0; i < m; i++) out[i] = (uint32_t)i;
+  uint64_t s = seed;
+  for (uint64_t i = m; i > 1; i--) {
+    uint64_t j = splitmix64(s) % i;
+    std::swap(out[i - 1], out[j]);
+  }
+}
+
+// One batch of vamana/index.h:188-316 (steps 1-4) on a HOST graph in the reference layout.
+// stats6: [search_dist_cmps, prune_dist_cmps, visited_total, t_search_us, t_prune_us, t_bidirect_us]
+int pann_oracle_vamana_insert_batch(const void* points, uint64_t n, uint32_t d, int dtype,
+                                    uint64_t stride, int metric, uint32_t* graph, uint32_t maxdeg,
+                                    const uint32_t* batch, uint64_t m, uint32_t start, uint32_t R,
+                                    uint32_t L, double alpha, uint64_t* stats6, int nthreads) {
+  if (R > maxdeg) return 1;
+  Dataset D{(const uint8_t*)points, n, d, dtype, stride, metric, graph, maxdeg};
+  SearchParams QP{0, (int64_t)L, 0.0, (int64_t)n, (int64_t)maxdeg};  // :250
+  std::vector<std::vector<uint32_t>> new_out(m);
+  std::atomic<uint64_t> sdc(0), pdc(0), vis(0);
+  auto t0 = std::chrono::steady_clock::now();
+  parallel_for(0, m, nthreads, [&](size_t i) {  // :247-266
+    uint32_t p = batch[i];
+    SearchResult Rs;
+    beam_search(D, D.row(p), (int64_t)p, &start, 1, QP, Rs);
+    sdc += Rs.dist_cmps; vis += Rs.visited.size();
+    uint64_t dc = 0;
+    std::vector<IdDist> cand = Rs.visited;
+    robust_prune(D, p, cand, alpha, R, true, new_out[i], &dc);
+    pdc += dc;
+  });
+  auto t1 = std::chrono::steady_clock::now();
+  const uint64_t rs = (uint64_t)maxdeg + 1;
+  parallel_for(0, m, nthreads, [&](size_t i) {  // :268-270
+    uint32_t* row = graph + batch[i] * rs;
+    row[0] = (uint32_t)new_out[i].size();
+    for (size_t j = 0; j < new_out[i].size(); j++) row[1 + j] = new_out[i][j];
+  });
+  // :278-282 reverse edges grouped by target.  Order inside a group (unspecified upstream):
+  // ascending position of the source in the batch -- the rule the product follows too.
+  std::vector<std::pair<uint32_t, uint32_t>> edges;  // (target, batch position)
+  for (size_t i = 0; i < m; i++)
+    for (uint32_t v : new_out[i]) edges.push_back({v, (uint32_t)i});
+  std::sort(edges.begin(), edges.end());
+  std::vector<size_t> gstart;
+  for (size_t e = 0; e < edges.size(); e++)
+    if (e == 0 || edges[e].first != edges[e - 1].first) gstart.push_back(e);
+  gstart.push_back(edges.size());
+  auto t2 = std::chrono::steady_clock::now();
+  parallel_for(0, gstart.size() - 1, nthreads, [&](size_t g) {  // :289-300
+    uint32_t v = edges[gstart[g]].first;
+    uint32_t* row = graph + v * rs;
+    std::vector<uint32_t> cids;
+    for (size_t e = gstart[g]; e < gstart[g + 1]; e++) cids.push_back(batch[edges[e].second]);
+    size_t newsize = cids.size() + row[0];
+    if (newsize <= R) {  // :292-294 add_neighbors_without_repeats(G[index], candidates)
+      std::vector<uint32_t> res = cids;
+      for (uint32_t j = 0; j < row[0]; j++)
+        if (std::find(cids.begin(), cids.end(), row[1 + j]) == cids.end()) res.push_back(row[1 + j]);
+      row[0] = (uint32_t)res.size();
+      for (size_t j = 0; j < res.size(); j++) row[1 + j] = res[j];
+    } else {  // :296-298 id-only robustPrune overload (:124-137)
+      uint64_t dc = 0;
+      std::vector<IdDist> cand;
+      for (uint32_t c : cids) { dc++; cand.push_back(IdDist{c, D.dist_ids(c, v)}); }
+      std::vector<uint32_t> out;
+      robust_prune(D, v, cand, alpha, R, true, out, &dc);
+      pdc += dc;
+      row[0] = (uint32_t)out.size();
+      for (size_t j = 0; j < out.size(); j++) row[1 + j] = out[j];
+    }
+  });
+  auto t3 = std::chrono::steady_clock::now();
+  if (stats6) {
+    auto us = [](auto a, auto b) { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+    stats6[0] += sdc; stats6[1] += pdc; stats6[2] += vis;
+    stats6[3] += us(t0, t1); stats6[4] += us(t2, t3); stats6[5] += us(t1, t2);
+  }
+  return 0;
+}
+
+// vamana/index.h:150-186 build_index + the batch schedule of :200-234.
+int pann_oracle_vamana_build(const void* points, uint64_t n, uint32_t d, int dtype, uint64_t stride,
+                             int metric, uint32_t* graph, uint32_t maxdeg, uint32_t R, uint32_t L,
+                             double alpha, int num_passes, uint64_t seed, int sort_neighbors,
+                             uint64_t* stats6, int nthreads) {
+  std::vector<uint32_t> perm(n);
+  pann_oracle_permutation(n, seed, perm.data());
+  // :206-209
+  size_t max_batch = std::min<size_t>((size_t)(0.02 * (double)(float)n), 1000000ul);
+  if (max_batch == 0) max_batch = n;
+  for (int pass = 0; pass < num_passes; pass++) {
+    double a = (pass == num_passes - 1) ? alpha : 1.0;  // :173-178
+    size_t count = 0, inc = 0, m = n;
+    while (count < m) {  // :223-234
+      size_t floor, ceiling;
+      if (std::pow(2.0, (double)inc) <= (double)max_batch) {
+        floor = (size_t)std::pow(2.0, (double)inc) - 1;
+        ceiling = std::min((size_t)std::pow(2.0, (double)(inc + 1)) - 1, m);
+        count = ceiling;
+      } else {
+        floor = count;
+        ceiling = std::min(count + max_batch, m);
+        count += max_batch;
+      }
+      int rc = pann_oracle_vamana_insert_batch(points, n, d, dtype, stride, metric, graph, maxdeg,
+                                               perm.data() + floor, ceiling - floor, 0, R, L, a,
+                                               stats6, nthreads);
+      if (rc) return rc;
+      inc++;
+    }
+  }
+  if (sort_neighbors) {  // :180-185; ties broken by id so the result is a function of the input
+    Dataset D{(const uint8_t*)points, n, d, dtype, stride, metric, graph, maxdeg};
+    parallel_for(0, n, nthreads, [&](size_t i) {
+      uint32_t* row = graph + i * (uint64_t)(maxdeg + 1);
+      std::vector<IdDist> v;
+      for (uint32_t j = 0; j < row[0]; j++) v.push_back(IdDist{row[1 + j], D.dist_ids((uint32_t)i, row[1 + j])});
+      std::sort(v.begin(), v.end(), less_id_dist);
+      for (uint32_t j = 0; j < row[0]; j++) row[1 + j] = v[j].id;
+    });
+  }
+  return 0;
+}
+
+// data_tools/compute_groundtruth.cpp:22-59: exact k nearest base points per query, sorted (dist,id).
+int pann_oracle_bruteforce_knn(const void* points, uint64_t n, uint32_t d, int dtype, uint64_t stride,
+                               int metric, const void* queries, uint64_t nq, uint64_t q_stride,
+                               uint32_t k, uint32_t* out_ids, float* out_dists, int nthreads) {
+  Dataset D{(const uint8_t*)points, n, d, dtype, stride, metric, nullptr, 0};
+  parallel_for(0, nq, nthreads, [&](size_t qi) {
+    const void* q = (const uint8_t*)queries + qi * q_stride;
+    std::vector<IdDist> all(n);
+    for (uint64_t i = 0; i < n; i++) all[i] = IdDist{(uint32_t)i, D.dist(q, (uint32_t)i)};
+    size_t kk = std::min<size_t>(k, n);
+    std::partial_sort(all.begin(), all.begin() + kk, all.end(), less_id_dist);
+    for (uint32_t j = 0; j < k; j++) {
+      out_ids[qi * k + j] = j < kk ? all[j].id : 0xFFFFFFFFu;
+      out_dists[qi * k + j] = j < kk ? all[j].dist : std::numeric_limits<float>::infinity();
+    }
+  });
+  return 0;
+}
+
+// hcnng_index.h:145-181: within one leaf (N ids) the m smallest (dist,id) among the other members.
+int pann_oracle_leaf_knn(const void* points, uint64_t n, uint32_t d, int dtype, uint64_t stride,
+                         int metric, const uint32_t* ids, uint32_t N, uint32_t m, uint32_t* out_ids,
+                         float* out_dists, int nthreads) {
+  Dataset D{(const uint8_t*)points, n, d, dtype, stride, metric, nullptr, 0};
+  parallel_for(0, N, nthreads, [&](size_t i) {
+    std::vector<IdDist> v;
+    for (uint32_t j = 0; j < N; j++)
+      if (j != i) v.push_back(IdDist{ids[j], D.dist_ids(ids[i], ids[j])});
+    size_t kk = std::min<size_t>(m, v.size());
+    std::partial_sort(v.begin(), v.begin() + kk, v.end(), less_id_dist);
+    for (uint32_t j = 0; j < m; j++) {
+      out_ids[i * m + j] = j < kk ? v[j].id : 0xFFFFFFFFu;
+      out_dists[i * m + j] = j < kk ? v[j].dist : std::numeric_limits<float>::infinity();
+    }
+  });
+  return 0;
+}
+
+// check_nn_recall.h:83-109 tie-aware recall: a returned id counts if it is among the first k
+// ground-truth ids or any later ground-truth entry whose distance equals the k-th distance.
+double pann_oracle_recall(const uint32_t* result_ids, uint32_t res_stride, const uint32_t* gt_ids,
+                          const float* gt_dists, uint32_t gt_k, uint64_t nq, uint32_t k) {
+  uint64_t hits = 0;
+  for (uint64_t i = 0; i < nq; i++) {
+    const uint32_t* g = gt_ids + i * gt_k; const float* gd = gt_dists + i * gt_k;
+    // the k first ground-truth entries plus every later one at the k-th distance (:89-98);
+    // each is counted once if it appears among the k reported ids (:99-106)
+    for (uint32_t t = 0; t < gt_k; t++) {
+      if (t >= k && !(gd[t] == gd[k - 1])) continue;
+      for (uint32_t j = 0; j < k; j++)
+        if (result_ids[i * res_stride + j] == g[t]) { hits++; break; }
+    }
+  }
+  return (double)hits / (double)(nq * k);
+}
+
+}  // extern "C"

@@ -1,0 +1,365 @@
+// api.hip -- the extern "C" boundary declared in include/pann.h: handle management (device
+// mirrors of PointRange / Graph), host<->device staging, and dispatch into the gfx950 kernels.
+// No CPU compute path exists here: without a HIP device every entry point fails loudly.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <vector>
+
+#include "pann_internal.h"
+
+namespace pann {
+
+static thread_local std::string g_err;
+void set_error(const std::string& s) { g_err = s; }
+int hip_fail(hipError_t e, const char* what) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return PANN_ERR_HIP;
+}
+
+int Workspace::ensure(size_t need) {
+  if (need <= bytes) return PANN_OK;
+  if (buf) { PANN_HIP(hipFree(buf)); buf = nullptr; bytes = 0; }
+  size_t cap = need + need / 4 + 4096;
+  PANN_HIP(hipMalloc(&buf, cap));
+  bytes = cap;
+  return PANN_OK;
+}
+void Workspace::release() { if (buf) (void)hipFree(buf); buf = nullptr; bytes = 0; }
+
+// a growable device buffer used for host-pointer entry points
+struct DevBuf {
+  void* p = nullptr; size_t bytes = 0;
+  int ensure(size_t need) {
+    if (need <= bytes) return PANN_OK;
+    if (p) { PANN_HIP(hipFree(p)); p = nullptr; bytes = 0; }
+    size_t cap = need + need / 4 + 256;
+    PANN_HIP(hipMalloc(&p, cap));
+    bytes = cap;
+    return PANN_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+  template <typename T> T* as() { return (T*)p; }
+};
+
+}  // namespace pann
+
+using namespace pann;
+
+struct pann_index {
+  DeviceIndex ix;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  Workspace ws;          // kernel scratch
+  DevBuf stage[12];      // staging for host-pointer calls
+  std::vector<uint32_t> hrow;  // host scratch
+};
+
+namespace {
+
+static uint32_t esize_of(int dtype) {
+  switch (dtype) { case PANN_U8: case PANN_I8: return 1; case PANN_F16: return 2; case PANN_F32: return 4; }
+  return 0;
+}
+
+struct DeviceGuard {
+  int prev = -1; bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+// reference layout n x (max_deg+1), slot 0 = degree  ->  device layout n x gstride, SENTINEL padded
+__global__ void graph_to_device_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                       uint64_t nrows, uint32_t max_deg, uint32_t gstride,
+                                       const uint32_t* __restrict__ row_ids) {
+  const uint64_t r = blockIdx.x;
+  if (r >= nrows) return;
+  const uint32_t* s = src + r * (uint64_t)(max_deg + 1);
+  const uint64_t target = row_ids ? row_ids[r] : r;
+  uint32_t* d = dst + target * (uint64_t)gstride;
+  const uint32_t deg = min(s[0], max_deg);
+  for (uint32_t i = threadIdx.x; i < gstride; i += blockDim.x) d[i] = (i < deg) ? s[1 + i] : SENTINEL;
+}
+
+__global__ void graph_to_host_layout_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                            uint64_t nrows, uint32_t max_deg, uint32_t gstride) {
+  const uint64_t r = blockIdx.x;
+  if (r >= nrows) return;
+  const uint32_t* s = src + r * (uint64_t)gstride;
+  uint32_t* d = dst + r * (uint64_t)(max_deg + 1);
+  // one wave per row: degree = number of non-sentinel slots (packed at the front)
+  uint32_t deg = 0;
+  for (uint32_t i0 = 0; i0 < gstride; i0 += 64) {
+    const uint32_t i = i0 + threadIdx.x;
+    const uint32_t a = i < gstride ? s[i] : SENTINEL;
+    deg += __popcll(__ballot(a != SENTINEL));
+    if (i < max_deg) d[1 + i] = (a != SENTINEL) ? a : 0u;   // Graph slabs are zero filled (graph.h:138)
+  }
+  if (threadIdx.x == 0) d[0] = deg;
+}
+
+__global__ void fill_u32_kernel(uint32_t* p, uint64_t n, uint32_t v) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) p[i] = v;
+}
+
+int check_idx(const pann_index* idx, const char* fn) {
+  if (!idx) { set_error(std::string(fn) + ": null index handle"); return PANN_ERR_BAD_ARG; }
+  return PANN_OK;
+}
+
+int upload_graph_rows(pann_index* idx, const uint32_t* h_rows, uint64_t m, const uint32_t* h_row_ids) {
+  DeviceIndex& ix = idx->ix;
+  if (m == 0) return PANN_OK;
+  const size_t row_bytes = (size_t)(ix.max_deg + 1) * 4;
+  // stream in slices so the staging buffer stays bounded (288 GB HBM, but host slabs can be huge)
+  const uint64_t slice = std::max<uint64_t>(1, (256ull << 20) / row_bytes);
+  for (uint64_t r0 = 0; r0 < m; r0 += slice) {
+    const uint64_t cnt = std::min(slice, m - r0);
+    int rc = idx->stage[0].ensure(cnt * row_bytes); if (rc) return rc;
+    PANN_HIP(hipMemcpyAsync(idx->stage[0].p, h_rows + r0 * (ix.max_deg + 1), cnt * row_bytes, hipMemcpyHostToDevice, idx->stream));
+    const uint32_t* d_ids = nullptr;
+    if (h_row_ids) {
+      rc = idx->stage[1].ensure(cnt * 4); if (rc) return rc;
+      PANN_HIP(hipMemcpyAsync(idx->stage[1].p, h_row_ids + r0, cnt * 4, hipMemcpyHostToDevice, idx->stream));
+      d_ids = idx->stage[1].as<uint32_t>();
+    }
+    uint32_t* dst = h_row_ids ? ix.graph : ix.graph + r0 * (uint64_t)ix.gstride;
+    hipLaunchKernelGGL(graph_to_device_kernel, dim3((uint32_t)cnt), dim3(64), 0, idx->stream,
+                       idx->stage[0].as<uint32_t>(), dst, cnt, ix.max_deg, ix.gstride, d_ids);
+    PANN_HIP(hipGetLastError());
+    PANN_HIP(hipStreamSynchronize(idx->stream));
+  }
+  return PANN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pann_abi_version(void) { return PANN_ABI_VERSION; }
+const char* pann_last_error(void) { return g_err.c_str(); }
+
+int pann_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int pann_index_create(pann_index** out, const void* points, uint64_t n, uint32_t d, int dtype,
+                      uint64_t row_stride_bytes, int metric, const uint32_t* graph,
+                      uint32_t max_deg, int device) {
+  if (!out || !points || n == 0 || d == 0) { set_error("pann_index_create: null/empty argument"); return PANN_ERR_BAD_ARG; }
+  const uint32_t es = esize_of(dtype);
+  if (es == 0) { set_error("pann_index_create: unknown dtype"); return PANN_ERR_BAD_ARG; }
+  if (metric != PANN_L2 && metric != PANN_MIPS) { set_error("pann_index_create: unknown metric"); return PANN_ERR_BAD_ARG; }
+  if (row_stride_bytes < (uint64_t)d * es) { set_error("pann_index_create: row stride smaller than a row"); return PANN_ERR_BAD_ARG; }
+  if (n >= 0x7FFFFFFFull) { set_error("pann_index_create: n must be < 2^31 (robustPrune uses int ids, vamana/index.h:97)"); return PANN_ERR_BAD_ARG; }
+  if (max_deg == 0 || max_deg > 4096) { set_error("pann_index_create: max_deg out of range [1,4096]"); return PANN_ERR_BAD_ARG; }
+  int ndev = pann_device_count();
+  if (ndev <= 0) { set_error("pann_index_create: no HIP device visible (this library has no CPU path)"); return PANN_ERR_NO_DEVICE; }
+  if (device < 0 || device >= ndev) { set_error("pann_index_create: device ordinal out of range"); return PANN_ERR_BAD_ARG; }
+  DeviceGuard g(device);
+  if (!g.ok) { set_error("pann_index_create: hipSetDevice failed"); return PANN_ERR_HIP; }
+
+  pann_index* idx = new pann_index();
+  idx->device = device;
+  DeviceIndex& ix = idx->ix;
+  ix.n = n; ix.d = d; ix.dtype = dtype; ix.metric = metric; ix.esize = es; ix.dbytes = d * es;
+  choose_point_layout(ix.dbytes, &ix.lpc, &ix.nch);
+  ix.pstride = ix.lpc * ix.nch * 16;
+  ix.max_deg = max_deg; ix.gstride = (max_deg + 15) / 16 * 16;
+  auto fail = [&](int rc) { pann_index_destroy(idx); return rc; };
+  if (hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(PANN_ERR_HIP); }
+  hipError_t e;
+  if ((e = hipMalloc((void**)&ix.points, n * (size_t)ix.pstride)) != hipSuccess) return fail(hip_fail(e, "hipMalloc(points)"));
+  if ((e = hipMalloc((void**)&ix.graph, n * (size_t)ix.gstride * 4)) != hipSuccess) return fail(hip_fail(e, "hipMalloc(graph)"));
+  // points: strided copy into the zero-padded device rows
+  if ((e = hipMemsetAsync(ix.points, 0, n * (size_t)ix.pstride, idx->stream)) != hipSuccess) return fail(hip_fail(e, "hipMemset(points)"));
+  if ((e = hipStreamSynchronize(idx->stream)) != hipSuccess) return fail(hip_fail(e, "sync"));
+  {
+    const uint64_t slice = std::max<uint64_t>(1, (1ull << 30) / std::max<uint64_t>(row_stride_bytes, 1));
+    for (uint64_t r0 = 0; r0 < n; r0 += slice) {
+      const uint64_t cnt = std::min(slice, n - r0);
+      e = hipMemcpy2D(ix.points + r0 * ix.pstride, ix.pstride, (const uint8_t*)points + r0 * row_stride_bytes,
+                      row_stride_bytes, ix.dbytes, cnt, hipMemcpyHostToDevice);
+      if (e != hipSuccess) return fail(hip_fail(e, "hipMemcpy2D(points)"));
+    }
+  }
+  if (graph) {
+    int rc = upload_graph_rows(idx, graph, n, nullptr);
+    if (rc) return fail(rc);
+  } else {
+    hipLaunchKernelGGL(fill_u32_kernel, dim3(2048), dim3(256), 0, idx->stream, ix.graph, n * (uint64_t)ix.gstride, SENTINEL);
+    if ((e = hipStreamSynchronize(idx->stream)) != hipSuccess) return fail(hip_fail(e, "fill graph"));
+  }
+  *out = idx;
+  return PANN_OK;
+}
+
+void pann_index_destroy(pann_index* idx) {
+  if (!idx) return;
+  DeviceGuard g(idx->device);
+  if (idx->stream) (void)hipStreamSynchronize(idx->stream);
+  if (idx->ix.points) (void)hipFree(idx->ix.points);
+  if (idx->ix.graph) (void)hipFree(idx->ix.graph);
+  idx->ws.release();
+  for (auto& s : idx->stage) s.release();
+  if (idx->stream) (void)hipStreamDestroy(idx->stream);
+  delete idx;
+}
+
+uint64_t pann_index_size(const pann_index* idx) { return idx ? idx->ix.n : 0; }
+uint32_t pann_index_dims(const pann_index* idx) { return idx ? idx->ix.d : 0; }
+uint32_t pann_index_max_degree(const pann_index* idx) { return idx ? idx->ix.max_deg : 0; }
+int pann_index_device(const pann_index* idx) { return idx ? idx->device : -1; }
+
+int pann_index_set_graph(pann_index* idx, const uint32_t* graph) {
+  if (int rc = check_idx(idx, "pann_index_set_graph")) return rc;
+  if (!graph) { set_error("pann_index_set_graph: null graph"); return PANN_ERR_BAD_ARG; }
+  DeviceGuard g(idx->device);
+  return upload_graph_rows(idx, graph, idx->ix.n, nullptr);
+}
+
+int pann_index_update_rows(pann_index* idx, const uint32_t* row_ids, const uint32_t* rows, uint64_t m) {
+  if (int rc = check_idx(idx, "pann_index_update_rows")) return rc;
+  if (m && (!row_ids || !rows)) { set_error("pann_index_update_rows: null argument"); return PANN_ERR_BAD_ARG; }
+  for (uint64_t i = 0; i < m; i++)
+    if (row_ids[i] >= idx->ix.n) { set_error("ERROR: graph index out of range"); return PANN_ERR_BAD_ARG; }  // graph.h:235-238
+  DeviceGuard g(idx->device);
+  return upload_graph_rows(idx, rows, m, row_ids);
+}
+
+int pann_index_get_graph(pann_index* idx, uint32_t* graph_out) {
+  if (int rc = check_idx(idx, "pann_index_get_graph")) return rc;
+  if (!graph_out) { set_error("pann_index_get_graph: null output"); return PANN_ERR_BAD_ARG; }
+  DeviceGuard g(idx->device);
+  DeviceIndex& ix = idx->ix;
+  const size_t row_bytes = (size_t)(ix.max_deg + 1) * 4;
+  const uint64_t slice = std::max<uint64_t>(1, (256ull << 20) / row_bytes);
+  for (uint64_t r0 = 0; r0 < ix.n; r0 += slice) {
+    const uint64_t cnt = std::min(slice, ix.n - r0);
+    if (int rc = idx->stage[0].ensure(cnt * row_bytes)) return rc;
+    hipLaunchKernelGGL(graph_to_host_layout_kernel, dim3((uint32_t)cnt), dim3(64), 0, idx->stream,
+                       ix.graph + r0 * (uint64_t)ix.gstride, idx->stage[0].as<uint32_t>(), cnt, ix.max_deg, ix.gstride);
+    PANN_HIP(hipGetLastError());
+    PANN_HIP(hipMemcpyAsync(graph_out + r0 * (ix.max_deg + 1), idx->stage[0].p, cnt * row_bytes, hipMemcpyDeviceToHost, idx->stream));
+    PANN_HIP(hipStreamSynchronize(idx->stream));
+  }
+  return PANN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// batched beam search
+// ---------------------------------------------------------------------------------------------
+
+static int search_common_checks(pann_index* idx, uint64_t nq, const pann_query_params* qp, const pann_search_out* out) {
+  if (int rc = check_idx(idx, "pann_batch_search")) return rc;
+  if (!qp || !out) { set_error("pann_batch_search: null params/out"); return PANN_ERR_BAD_ARG; }
+  if (qp->k > qp->beam) {  // beamSearch.h:368-372, :549-553
+    set_error("Error: beam search parameter Q = " + std::to_string(qp->beam) + " same size or smaller than k = " + std::to_string(qp->k));
+    return PANN_ERR_BAD_ARG;
+  }
+  (void)nq;
+  return PANN_OK;
+}
+
+int pann_batch_search_dev(pann_index* idx, const void* d_queries, const uint32_t* d_query_ids,
+                          uint64_t nq, uint64_t q_stride_bytes, const uint32_t* d_starts,
+                          uint32_t nstarts, const pann_query_params* qp,
+                          const pann_search_out* d_out, void* stream) {
+  if (int rc = search_common_checks(idx, nq, qp, d_out)) return rc;
+  if (!d_starts) { set_error("beam search expects at least one start point"); return PANN_ERR_BAD_ARG; }
+  if (d_queries && q_stride_bytes < idx->ix.dbytes) { set_error("pann_batch_search: query stride smaller than a row"); return PANN_ERR_BAD_ARG; }
+  DeviceGuard g(idx->device);
+  SearchArgs a;
+  a.queries = (const uint8_t*)d_queries; a.qstride = q_stride_bytes; a.query_ids = d_query_ids;
+  a.nq = nq; a.starts = d_starts; a.nstarts = nstarts;
+  a.k = qp->k; a.beam = qp->beam; a.limit = qp->limit; a.degree_limit = qp->degree_limit; a.cut = qp->cut;
+  a.out = *d_out;
+  if (int rc = idx->ws.ensure(search_workspace_bytes(idx->ix, a))) return rc;
+  return launch_beam_search(idx->ix, a, idx->ws.buf, idx->ws.bytes, (hipStream_t)stream);
+}
+
+int pann_batch_search(pann_index* idx, const void* queries, const uint32_t* query_ids, uint64_t nq,
+                      uint64_t q_stride_bytes, const uint32_t* starts, uint32_t nstarts,
+                      const pann_query_params* qp, const pann_search_out* out) {
+  if (int rc = search_common_checks(idx, nq, qp, out)) return rc;
+  if (!starts || nstarts == 0) { set_error("beam search expects at least one start point"); return PANN_ERR_BAD_ARG; }
+  if ((queries == nullptr) == (query_ids == nullptr)) { set_error("pann_batch_search: exactly one of queries / query_ids must be given"); return PANN_ERR_BAD_ARG; }
+  for (uint32_t i = 0; i < nstarts; i++)
+    if (starts[i] >= idx->ix.n) { set_error("pann_batch_search: start point out of range"); return PANN_ERR_BAD_ARG; }
+  if (query_ids)
+    for (uint64_t i = 0; i < nq; i++)
+      if (query_ids[i] >= idx->ix.n) { set_error("pann_batch_search: query id out of range"); return PANN_ERR_BAD_ARG; }
+  if (nq == 0) return PANN_OK;
+  DeviceGuard g(idx->device);
+  hipStream_t st = idx->stream;
+  const DeviceIndex& ix = idx->ix;
+  // stage inputs
+  const void* d_q = nullptr; const uint32_t* d_qid = nullptr;
+  if (queries) {
+    if (q_stride_bytes < ix.dbytes) { set_error("pann_batch_search: query stride smaller than a row"); return PANN_ERR_BAD_ARG; }
+    if (int rc = idx->stage[2].ensure(nq * q_stride_bytes + 16)) return rc;
+    PANN_HIP(hipMemcpyAsync(idx->stage[2].p, queries, (nq - 1) * q_stride_bytes + ix.dbytes, hipMemcpyHostToDevice, st));
+    d_q = idx->stage[2].p;
+  } else {
+    if (int rc = idx->stage[2].ensure(nq * 4)) return rc;
+    PANN_HIP(hipMemcpyAsync(idx->stage[2].p, query_ids, nq * 4, hipMemcpyHostToDevice, st));
+    d_qid = idx->stage[2].as<uint32_t>();
+  }
+  if (int rc = idx->stage[3].ensure((size_t)nstarts * 4)) return rc;
+  PANN_HIP(hipMemcpyAsync(idx->stage[3].p, starts, (size_t)nstarts * 4, hipMemcpyHostToDevice, st));
+  // device outputs
+  pann_search_out d = *out;
+  const size_t ok = out->out_k, vc = out->visited_cap;
+  auto want = [&](DevBuf& b, const void* host, size_t bytes, void** dptr) -> int {
+    *dptr = nullptr;
+    if (!host || bytes == 0) return PANN_OK;
+    if (int rc = b.ensure(bytes)) return rc;
+    *dptr = b.p; return PANN_OK;
+  };
+  void *p_ids, *p_d, *p_fs, *p_vc, *p_dc, *p_ds, *p_vi, *p_vd;
+  if (int rc = want(idx->stage[4], out->ids, nq * ok * 4, &p_ids)) return rc;
+  if (int rc = want(idx->stage[5], out->dists, nq * ok * 4, &p_d)) return rc;
+  if (int rc = want(idx->stage[6], out->frontier_size, nq * 4, &p_fs)) return rc;
+  if (int rc = want(idx->stage[7], out->visited_count, nq * 4, &p_vc)) return rc;
+  if (int rc = want(idx->stage[8], out->dist_cmps, nq * 4, &p_dc)) return rc;
+  if (int rc = want(idx->stage[9], out->degree_sum, nq * 4, &p_ds)) return rc;
+  if (int rc = want(idx->stage[10], out->visited_ids, nq * vc * 4, &p_vi)) return rc;
+  if (int rc = want(idx->stage[11], out->visited_dists, nq * vc * 4, &p_vd)) return rc;
+  d.ids = (uint32_t*)p_ids; d.dists = (float*)p_d; d.frontier_size = (uint32_t*)p_fs;
+  d.visited_count = (uint32_t*)p_vc; d.dist_cmps = (uint32_t*)p_dc; d.degree_sum = (uint32_t*)p_ds;
+  d.visited_ids = (uint32_t*)p_vi; d.visited_dists = (float*)p_vd;
+  if (!p_vi && !p_vd) d.visited_cap = 0;
+
+  int rc = pann_batch_search_dev(idx, d_q, d_qid, nq, q_stride_bytes, idx->stage[3].as<uint32_t>(), nstarts, qp, &d, st);
+  if (rc) return rc;
+  auto back = [&](void* host, void* dev, size_t bytes) -> hipError_t {
+    if (!host || !dev || !bytes) return hipSuccess;
+    return hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st);
+  };
+  PANN_HIP(back(out->ids, p_ids, nq * ok * 4));
+  PANN_HIP(back(out->dists, p_d, nq * ok * 4));
+  PANN_HIP(back(out->frontier_size, p_fs, nq * 4));
+  PANN_HIP(back(out->visited_count, p_vc, nq * 4));
+  PANN_HIP(back(out->dist_cmps, p_dc, nq * 4));
+  PANN_HIP(back(out->degree_sum, p_ds, nq * 4));
+  PANN_HIP(back(out->visited_ids, p_vi, nq * vc * 4));
+  PANN_HIP(back(out->visited_dists, p_vd, nq * vc * 4));
+  uint32_t status = 0;
+  PANN_HIP(hipMemcpyAsync(&status, (uint8_t*)idx->ws.buf + 64, 4, hipMemcpyDeviceToHost, st));
+  PANN_HIP(hipStreamSynchronize(st));
+  if (status & 1u) { set_error("pann_batch_search: visited list longer than visited_cap"); return PANN_ERR_OVERFLOW; }
+  if (status & 2u) { set_error("pann_batch_search: internal dropped-list overflow"); return PANN_ERR_OVERFLOW; }
+  return PANN_OK;
+}
+
+}  // extern "C"

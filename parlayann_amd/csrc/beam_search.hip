@@ -1,0 +1,566 @@
+// beam_search.hip -- batched greedy beam search on gfx950: ONE WAVEFRONT PER QUERY.
+//
+// Replaces the parallel_for over queries of searchAll/qsearchAll (beamSearch.h:374,556) and the
+// per-insert searches of Vamana's batch_insert (vamana/index.h:247-259); each wave runs the exact
+// state machine of filtered_beam_search (beamSearch.h:22-214, use_filtering == false):
+//
+//   frontier F[<=beam]  sorted (dist,id) keys in LDS, one "visited" flag per entry
+//   filter   H[1<<bits] the reference's lossy direct-mapped table (LDS up to 16 KB, else HBM)
+//   cands    C[...]     survivors of `dist < cutoff`, accumulated across skipped merges (:162-168)
+//
+// Per iteration: pick first unvisited frontier entry -> one aligned read of its adjacency row
+// (lane i <- neighbour i) -> wave-parallel replay of the SEQUENTIAL filter update (:130-136) ->
+// gather distances, LPC lanes x 16 B per candidate vector so every load instruction covers whole
+// rows (coalesced 64..512 B segments) -> ballot-compaction of candidates -> rank-based merge.
+//
+// Equivalences used (proved in DESIGN.md "Kernel 1"):
+//  * unvisited_frontier[offset] (:109) == first frontier entry whose flag is clear, because the
+//    frontier does not change between merges and the skipped entries are exactly the flagged ones.
+//  * set_difference(frontier, visited) (:203-208) == entries with flag clear, provided an entry
+//    that re-enters the frontier after having been visited gets its flag back.  That can only
+//    happen while the frontier is not full (cut-prune :190-195 dropped it); such entries are kept
+//    in a small per-query "dropped" list and candidates are checked against it.
+#include "pann_device.h"
+
+namespace pann {
+
+struct BSParams {
+  const uint8_t* points; uint32_t pstride; uint32_t dbytes; uint32_t nch;
+  const uint32_t* graph; uint32_t gstride; uint32_t max_deg;
+  const uint8_t* queries; uint64_t qstride; const uint32_t* query_ids;
+  const uint32_t* starts; uint32_t nstarts;
+  uint32_t nq;
+  uint32_t k, beam, limit, degree_limit; double cut;
+  uint32_t skip_enabled;   // QP.limit >= 2*beam (:163)
+  uint32_t cut_enabled;    // QP.k > 0 && is_metric() (:190)
+  uint32_t bits;           // log2 of filter size (:52)
+  uint32_t bcap, ccap;     // LDS capacities (multiples of 64)
+  uint32_t* hash_global;   // [slots][1<<bits] when the filter does not fit LDS
+  uint64_t* dropped; uint32_t dcap;  // [nq][dcap] visited entries that left a non-full frontier
+  uint32_t* work_counter;  // persistent variant: next query to take
+  uint32_t* status;        // [0] |= 1 on visited-list overflow, |= 2 on dropped-list overflow
+  pann_search_out out;
+};
+
+__device__ __forceinline__ uint32_t lanes_below(uint64_t m, int lane) {
+  return __popcll(m & ((1ull << lane) - 1ull));
+}
+
+template <bool HASH_LDS>
+__device__ __forceinline__ uint32_t hload(const uint32_t* H, uint32_t s) {
+  if constexpr (HASH_LDS) return H[s];
+  else return __hip_atomic_load(H + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool HASH_LDS>
+__device__ __forceinline__ void hstore(uint32_t* H, uint32_t s, uint32_t v) {
+  if constexpr (HASH_LDS) H[s] = v;
+  else __hip_atomic_store(H + s, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool HASH_LDS>
+__device__ __forceinline__ void hsync() {
+  if constexpr (!HASH_LDS) __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): global table ops retire in order
+  __syncthreads();
+}
+
+// first index in sorted A[0..n) with A[i] >= key
+__device__ __forceinline__ uint32_t lower_bound_lds(const uint64_t* A, uint32_t n, uint64_t key) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (A[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// Replay of `for a in row: has_been_seen(a)` (:54-59,:131-136) for up to 64 ids held one per lane.
+// Sequential semantics: after lane j is processed table[s_j] == a_j whether or not it was a hit, so
+// lane i is a hit iff the LAST earlier lane with the same slot holds the same id, or, when there is
+// none, iff the table held a_i on entry.  Returns "seen" per lane and leaves the table as the
+// sequential loop would.
+template <bool HASH_LDS>
+__device__ __forceinline__ bool filter_update(uint32_t* H, uint32_t hmask, bool active, uint32_t a, int lane) {
+  const uint32_t s = (uint32_t)hash64_2((uint64_t)a) & hmask;
+  uint32_t old = active ? hload<HASH_LDS>(H, s) : 0u;
+  hsync<HASH_LDS>();
+  if (active) hstore<HASH_LDS>(H, s, (uint32_t)lane);   // some lane of each slot group wins
+  hsync<HASH_LDS>();
+  uint32_t w = active ? hload<HASH_LDS>(H, s) : (uint32_t)lane;
+  uint64_t losers = __ballot(active && w != (uint32_t)lane);
+  int prev = -1;       // last earlier lane with my slot
+  bool last = true;    // no later lane with my slot
+  while (losers) {     // one trip per slot shared by >1 lane (about 2 per 64 ids at 1024 slots)
+    const int L = __ffsll((unsigned long long)losers) - 1;
+    const uint32_t sL = __builtin_amdgcn_readlane(s, L);
+    const uint64_t grp = __ballot(active && s == sL);
+    losers &= ~grp;
+    if (active && s == sL) {
+      const uint64_t below = grp & ((1ull << lane) - 1ull);
+      prev = below ? 63 - __clzll((unsigned long long)below) : -1;
+      last = (lane == 63) ? true : ((grp >> (lane + 1)) == 0ull);
+    }
+  }
+  const uint32_t a_prev = __shfl(a, prev < 0 ? lane : prev);
+  const bool seen = active && (prev >= 0 ? (a_prev == a) : (old == a));
+  hsync<HASH_LDS>();
+  if (active && last) hstore<HASH_LDS>(H, s, a);
+  hsync<HASH_LDS>();
+  return seen;
+}
+
+// Distances from the query (registers qreg / LDS qlds) to the m ids in Pl[0..m); survivors of
+// `dist < cutoff` (:157) are appended to C.  LPC lanes share one candidate: each reads 16 B per
+// chunk, so one load instruction fetches 64/LPC complete row segments.
+template <int DT, int METRIC, int LPC, bool NCH1, int U>
+__device__ __forceinline__ uint32_t gather_distances(const BSParams& P, const uint4& qreg,
+                                                     const uint4* qlds, const uint32_t* Pl, uint32_t m,
+                                                     uint32_t cutoff_ord, uint64_t* C, uint32_t c, int lane) {
+  using acc_t = typename AccT<DT>::type;
+  constexpr int G = PANN_WAVE / LPC;
+  const int grp = lane / LPC, sub = lane % LPC;
+  for (uint32_t s0 = 0; s0 < m; s0 += G * U) {
+    acc_t acc[U];
+    uint32_t ids[U];
+    if constexpr (NCH1) {
+      uint4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t ci = s0 + u * G + grp;
+        ids[u] = ci < m ? Pl[ci] : SENTINEL;
+        v[u] = make_uint4(0, 0, 0, 0);
+        if (ci < m) v[u] = *reinterpret_cast<const uint4*>(P.points + (uint64_t)ids[u] * P.pstride + sub * 16);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) { acc[u] = 0; dist_accum<DT, METRIC>(acc[u], v[u], qreg); }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t ci = s0 + u * G + grp;
+        ids[u] = ci < m ? Pl[ci] : SENTINEL;
+        acc[u] = 0;
+      }
+      for (uint32_t ch = 0; ch < P.nch; ch++) {
+        uint4 v[U];
+        const uint4 qv = qlds[ch * LPC + sub];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          v[u] = make_uint4(0, 0, 0, 0);
+          if (ids[u] != SENTINEL)
+            v[u] = *reinterpret_cast<const uint4*>(P.points + (uint64_t)ids[u] * P.pstride + (ch * LPC + sub) * 16);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) dist_accum<DT, METRIC>(acc[u], v[u], qv);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const acc_t tot = group_sum<LPC>(acc[u]);
+      const float dist = dist_finish<DT, METRIC>(tot);
+      const uint32_t ord = f2ord(dist);
+      const bool pass = (sub == 0) && (ids[u] != SENTINEL) && (ord < cutoff_ord);
+      const uint64_t pm = __ballot(pass);
+      if (pass) C[c + lanes_below(pm, lane)] = ((uint64_t)ord << 32) | ids[u];
+      c += __popcll(pm);
+    }
+  }
+  return c;
+}
+
+template <int DT, int METRIC, int LPC, bool NCH1, bool HASH_LDS>
+__global__ void __launch_bounds__(PANN_WAVE) beam_search_kernel(BSParams P) {
+  const int lane = threadIdx.x;
+  extern __shared__ __align__(16) uint8_t smem[];
+  // ---- LDS carve (all regions 16 B aligned) ----
+  uint64_t* F = reinterpret_cast<uint64_t*>(smem);       // [bcap] frontier keys
+  uint64_t* NF = F + P.bcap;                             // [bcap] merge output (swapped with F)
+  uint64_t* C = NF + P.bcap;                             // [ccap] candidates (unsorted)
+  uint64_t* S = C + P.ccap;                              // [ccap] valid candidates, sorted
+  uint32_t* Fv = reinterpret_cast<uint32_t*>(S + P.ccap);  // [bcap] 0 unvisited, 1 visited, 2 visited+listed
+  uint32_t* NFv = Fv + P.bcap;                           // [bcap]
+  uint32_t* CP = NFv + P.bcap;                           // [ccap] candidate's lower_bound in F
+  uint32_t* Pl = CP + P.ccap;                            // [64] filter survivors of one row chunk
+  uint4* qlds = reinterpret_cast<uint4*>(Pl + 64);       // [nch*LPC] query (generic variant)
+  uint32_t* Hl = reinterpret_cast<uint32_t*>(qlds + (NCH1 ? 0 : P.nch * LPC));  // [1<<bits] if HASH_LDS
+
+  const uint32_t hsize = 1u << P.bits, hmask = hsize - 1u;
+  const uint32_t beam = P.beam;
+  const uint32_t BIG_ORD = f2ord(2147483648.0f);  // (distanceType) numeric_limits<int>::max()  (:152)
+
+  uint32_t qi = blockIdx.x;
+  if constexpr (!HASH_LDS) {  // persistent: one filter slot per block, queries pulled from a counter
+    qi = 0;
+    if (lane == 0) qi = atomicAdd(P.work_counter, 1u);
+    qi = __builtin_amdgcn_readfirstlane(qi);
+  }
+  while (qi < P.nq) {
+    uint32_t* H = HASH_LDS ? Hl : P.hash_global + ((size_t)blockIdx.x << P.bits);
+    // ---- filter init: hash_filter(1<<bits, -1) (:53) ----
+    for (uint32_t i = lane; i < hsize; i += PANN_WAVE) hstore<HASH_LDS>(H, i, SENTINEL);
+
+    // ---- query vector -> registers (one chunk) or LDS (generic) ----
+    const int64_t self = P.query_ids ? (int64_t)P.query_ids[qi] : -1;
+    const uint8_t* qrow = P.query_ids ? P.points + (uint64_t)self * P.pstride : P.queries + (uint64_t)qi * P.qstride;
+    const bool qaligned = ((reinterpret_cast<uintptr_t>(qrow) & 15) == 0);
+    const uint32_t qvalid = P.dbytes;
+    uint4 qreg = make_uint4(0, 0, 0, 0);
+    const int sub = lane % LPC;
+    if constexpr (NCH1) {
+      qreg = load16_guarded(qrow, sub * 16, qaligned ? qvalid : 0u);
+      if (!qaligned) {
+        uint8_t tmp[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) tmp[i] = (sub * 16 + i < (int)qvalid) ? qrow[sub * 16 + i] : (uint8_t)0;
+        __builtin_memcpy(&qreg, tmp, 16);
+      }
+    } else {
+      for (uint32_t j = lane; j < P.nch * LPC; j += PANN_WAVE) {
+        uint4 v = load16_guarded(qrow, j * 16, qaligned ? qvalid : 0u);
+        if (!qaligned) {
+          uint8_t tmp[16];
+#pragma unroll
+          for (int i = 0; i < 16; i++) tmp[i] = (j * 16 + i < qvalid) ? qrow[j * 16 + i] : (uint8_t)0;
+          __builtin_memcpy(&v, tmp, 16);
+        }
+        qlds[j] = v;
+      }
+    }
+    hsync<HASH_LDS>();
+
+    uint32_t f = 0;        // frontier size
+    uint32_t c = 0;        // accumulated candidates
+    uint32_t nvis = 0;     // num_visited
+    uint32_t dcmps = P.nstarts;  // dist_cmps == full_dist_cmps (:83-84)
+    uint32_t degsum = 0;
+    uint32_t ndrop = 0;    // entries in the dropped list
+    uint64_t* DL = P.dropped + (size_t)qi * P.dcap;
+
+    // ---- start points (:66-70): distance for each, filter insert in order, then "merge" into
+    // the empty frontier (which sorts them) ----
+    for (uint32_t s0 = 0; s0 < P.nstarts; s0 += PANN_WAVE) {
+      const uint32_t i = s0 + lane;
+      const bool act = i < P.nstarts;
+      const uint32_t a = act ? P.starts[i] : 0u;
+      (void)filter_update<HASH_LDS>(H, hmask, act, a, lane);
+      if (act) Pl[lane] = a;
+      __syncthreads();
+      const uint32_t m = min(P.nstarts - s0, (uint32_t)PANN_WAVE);
+      // every start enters the frontier: cutoff above any finite distance
+      c = gather_distances<DT, METRIC, LPC, NCH1, 4>(P, qreg, qlds, Pl, m, 0xFFFFFFFFu, C, c, lane);
+      __syncthreads();
+    }
+
+    bool first = true;  // the start-point pseudo-merge: no cut-prune, no visit
+    for (;;) {
+      bool do_merge = first;
+      if (!first) {
+        // ---- next vertex: first unvisited frontier entry (:107-109) ----
+        int cur_idx = -1;
+        uint32_t unv_total = 0;
+        for (uint32_t e0 = 0; e0 < f; e0 += PANN_WAVE) {
+          const uint32_t e = e0 + lane;
+          const uint64_t um = __ballot(e < f && Fv[e] == 0u);
+          if (cur_idx < 0 && um) cur_idx = (int)e0 + __ffsll((unsigned long long)um) - 1;
+          unv_total += __popcll(um);
+        }
+        if (cur_idx < 0 || nvis >= P.limit) break;
+        const uint64_t cur_key = F[cur_idx];
+        const uint32_t cur = key_id(cur_key);
+        // ---- visited.insert(current) (:112-114) ----
+        if (lane == 0) {
+          Fv[cur_idx] = 1u;
+          if (P.out.visited_cap) {
+            if (nvis < P.out.visited_cap) {
+              if (P.out.visited_ids) P.out.visited_ids[(size_t)qi * P.out.visited_cap + nvis] = cur;
+              if (P.out.visited_dists) P.out.visited_dists[(size_t)qi * P.out.visited_cap + nvis] = key_dist(cur_key);
+            } else {
+              atomicOr(P.status, 1u);
+            }
+          }
+        }
+        nvis++;
+        const bool more_unvisited = unv_total > 1;         // offset + 1 < remain (:165)
+        const bool full = (f == beam);                      // :115
+        const uint32_t cutoff_ord = full ? (uint32_t)(F[f - 1] >> 32) : BIG_ORD;  // :150-152
+
+        // ---- adjacency row: lane i <- slot i; degree = number of non-sentinel slots ----
+        const uint32_t* row = P.graph + (size_t)cur * P.gstride;
+        for (uint32_t i0 = 0; i0 < P.gstride; i0 += PANN_WAVE) {
+          const uint32_t i = i0 + lane;
+          uint32_t a = SENTINEL;
+          if (i < P.gstride) a = row[i];
+          const bool act = (a != SENTINEL) && (i < P.degree_limit);   // min(size, degree_limit) (:130)
+          const uint64_t am = __ballot(act);
+          if (am == 0ull) break;
+          degsum += __popcll(am);
+          const bool seen = filter_update<HASH_LDS>(H, hmask, act, a, lane);
+          const bool keep = act && !seen && ((int64_t)a != self);     // :133
+          const uint64_t km = __ballot(keep);
+          const uint32_t m = __popcll(km);
+          if (keep) Pl[lanes_below(km, lane)] = a;
+          dcmps += m;                                                 // :137,155
+          __syncthreads();
+          if (m) c = gather_distances<DT, METRIC, LPC, NCH1, 4>(P, qreg, qlds, Pl, m, cutoff_ord, C, c, lane);
+          __syncthreads();
+        }
+        // ---- skip the merge while too few candidates (:162-168) ----
+        __syncthreads();
+        const bool skip = (c == 0) || (P.skip_enabled && c < beam / 8 && more_unvisited);
+        do_merge = !skip;
+      }
+      if (do_merge) {
+        // ================= merge: sort+unique(C), set_union with F, trim (:173-185) =========
+        // A1: kill duplicates (same id <=> same key) and entries already in F; remember rank in F
+        for (uint32_t j0 = 0; j0 < c; j0 += PANN_WAVE) {
+          const uint32_t j = j0 + lane;
+          uint64_t key = KEY_INF;
+          uint32_t p = 0;
+          if (j < c) {
+            key = C[j];
+            bool dead = false;
+            for (uint32_t i = 0; i < j; i++) dead |= (C[i] == key);
+            p = lower_bound_lds(F, f, key);
+            dead |= (p < f && F[p] == key);
+            if (dead) key = KEY_INF;
+          }
+          __syncthreads();       // all reads of C[0..j) by this chunk are done
+          if (j < c) { C[j] = key; CP[j] = p; }
+          // later chunks compare against earlier ORIGINAL keys; a killed earlier key was itself a
+          // duplicate of a still earlier live one (or of F), so the verdict is unchanged.
+          __syncthreads();
+        }
+        // A2: rank among live candidates -> sorted S, and direct placement into NF
+        uint32_t nvalid = 0;
+        for (uint32_t j0 = 0; j0 < c; j0 += PANN_WAVE) {
+          const uint32_t j = j0 + lane;
+          const uint64_t key = j < c ? C[j] : KEY_INF;
+          nvalid += __popcll(__ballot(key != KEY_INF));
+        }
+        for (uint32_t j0 = 0; j0 < c; j0 += PANN_WAVE) {
+          const uint32_t j = j0 + lane;
+          const uint64_t key = j < c ? C[j] : KEY_INF;
+          if (key != KEY_INF) {
+            uint32_t r = 0;
+            for (uint32_t i = 0; i < c; i++) r += (C[i] < key) ? 1u : 0u;
+            S[r] = key;
+            const uint32_t pos = r + CP[j];
+            if (pos < beam) {
+              uint32_t flag = 0u;   // re-entry of an already visited vertex? (only while not full)
+              for (uint32_t t = 0; t < ndrop; t++)
+                flag |= (__hip_atomic_load(DL + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key) ? 2u : 0u;
+              NF[pos] = key; NFv[pos] = flag;
+            }
+          }
+        }
+        __syncthreads();
+        // B: old frontier entries move right by the number of live candidates below them
+        for (uint32_t e0 = 0; e0 < f; e0 += PANN_WAVE) {
+          const uint32_t e = e0 + lane;
+          if (e < f) {
+            const uint64_t key = F[e];
+            const uint32_t pos = e + lower_bound_lds(S, nvalid, key);
+            if (pos < beam) { NF[pos] = key; NFv[pos] = Fv[e]; }
+          }
+        }
+        __syncthreads();
+        const uint32_t f_old = f;
+        uint32_t f_new = min(f_old + nvalid, beam);   // :185
+        // ---- cut-prune (:190-195) ----
+        if (!first && P.cut_enabled && f_new > P.k) {
+          const float dk = key_dist(NF[P.k]);
+          const float thr = (float)(P.cut * (double)dk);
+          const uint64_t thr_key = (uint64_t)f2ord(thr) << 32;   // pair{0, thr}: kept iff key <= thr_key
+          uint32_t ub = 0;
+          for (uint32_t e0 = 0; e0 < f_new; e0 += PANN_WAVE) {
+            const uint32_t e = e0 + lane;
+            ub += __popcll(__ballot(e < f_new && NF[e] <= thr_key));
+          }
+          f_new = max(ub, f_old);
+        }
+        // ---- visited entries that fall off a frontier that is still not full can come back:
+        // remember them (see file header).  Once full, nothing dropped can ever re-enter. ----
+        if (f_new == beam) {
+          ndrop = 0;
+        } else if (P.cut_enabled && !first) {
+          for (uint32_t e0 = 0; e0 < f_old; e0 += PANN_WAVE) {
+            const uint32_t e = e0 + lane;
+            bool lost = false;
+            uint64_t key = 0;
+            if (e < f_old && Fv[e] == 1u) {
+              key = F[e];
+              const uint32_t pos = e + lower_bound_lds(S, nvalid, key);
+              lost = pos >= f_new;
+            }
+            const uint64_t lm = __ballot(lost);
+            if (lost) {
+              const uint32_t at = ndrop + lanes_below(lm, lane);
+              if (at < P.dcap) DL[at] = key; else atomicOr(P.status, 2u);
+            }
+            ndrop = min(ndrop + (uint32_t)__popcll(lm), P.dcap);
+          }
+          // entries already listed (flag 2) stay listed; nothing to do for them
+          __builtin_amdgcn_s_waitcnt(0);   // dropped-list stores visible to this wave's later loads
+        }
+        // visited entries with flag 2 that stay in the frontier keep flag 2 (== visited)
+        { uint64_t* t = F; F = NF; NF = t; uint32_t* tv = Fv; Fv = NFv; NFv = tv; }
+        f = f_new;
+        c = 0;                      // candidates.clear() (:182)
+        __syncthreads();
+      }
+      first = false;
+    }
+
+    // ---- outputs (:211-213; searchAll takes the first k ids :378-380) ----
+    const size_t qo = (size_t)qi * P.out.out_k;
+    for (uint32_t j = lane; j < P.out.out_k; j += PANN_WAVE) {
+      const bool ok = j < f;
+      const uint64_t key = ok ? F[j] : 0ull;
+      if (P.out.ids) P.out.ids[qo + j] = ok ? key_id(key) : SENTINEL;
+      if (P.out.dists) P.out.dists[qo + j] = ok ? key_dist(key) : __builtin_inff();
+    }
+    if (lane == 0) {
+      if (P.out.frontier_size) P.out.frontier_size[qi] = f;
+      if (P.out.visited_count) P.out.visited_count[qi] = nvis;
+      if (P.out.dist_cmps) P.out.dist_cmps[qi] = dcmps;
+      if (P.out.degree_sum) P.out.degree_sum[qi] = degsum;
+    }
+    __syncthreads();
+    if constexpr (HASH_LDS) break;
+    else {
+      qi = 0;
+      if (lane == 0) qi = atomicAdd(P.work_counter, 1u);
+      qi = __builtin_amdgcn_readfirstlane(qi);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side: layout choice, LDS budget, dispatch
+// ---------------------------------------------------------------------------------------------
+
+// Lanes-per-candidate and chunks-per-lane for a row of dbytes.  One chunk (query in registers)
+// whenever the row is 128/256/512 B after padding to 16*LPC; otherwise LPC=4 (64-B granules,
+// the reference's own row alignment, point_range.h:94) or LPC=16 for long rows.
+void choose_point_layout(uint32_t dbytes, uint32_t* lpc, uint32_t* nch) {
+  const uint32_t r64 = (dbytes + 63) / 64 * 64;
+  if (r64 == 128) { *lpc = 8; *nch = 1; return; }
+  if (r64 == 256) { *lpc = 16; *nch = 1; return; }
+  if (r64 == 512) { *lpc = 32; *nch = 1; return; }
+  if (r64 % 256 == 0) { *lpc = 16; *nch = r64 / 256; return; }
+  *lpc = 4; *nch = r64 / 64;
+}
+
+static uint32_t filter_bits(int64_t beam) {  // :52
+  double l = std::ceil(std::log2((double)beam * (double)beam)) - 2.0;
+  int b = (int)l;
+  return (uint32_t)(b < 10 ? 10 : b);
+}
+
+struct Plan {
+  uint32_t bits, bcap, ccap, deg_eff, dcap, lds_bytes; bool hash_lds; uint32_t slots;
+};
+
+static Plan make_plan(const DeviceIndex& ix, const SearchArgs& a) {
+  Plan p;
+  p.bits = filter_bits(a.beam);
+  const uint32_t beam = (uint32_t)a.beam;
+  p.bcap = (std::max<uint32_t>(beam, a.nstarts) + 63) / 64 * 64;
+  int64_t dl = std::min<int64_t>(std::max<int64_t>(a.degree_limit, 0), (int64_t)ix.max_deg);
+  p.deg_eff = (uint32_t)dl;
+  // at merge time |C| <= (beam/8 - 1) + deg_eff (accumulation stops at beam/8); starts first
+  p.ccap = (std::max<uint32_t>(beam / 8 + p.deg_eff, a.nstarts) + 63) / 64 * 64 + 64;
+  p.dcap = 256;
+  const bool nch1 = (ix.nch == 1);
+  size_t fixed = (size_t)p.bcap * 8 * 2 + (size_t)p.ccap * 8 * 2 + (size_t)p.bcap * 4 * 2 +
+                 (size_t)p.ccap * 4 + 64 * 4 + (nch1 ? 0 : (size_t)ix.nch * ix.lpc * 16);
+  size_t hbytes = (size_t)4 << p.bits;
+  p.hash_lds = (hbytes <= 16384) && (fixed + hbytes <= 64 * 1024);
+  p.lds_bytes = (uint32_t)(fixed + (p.hash_lds ? hbytes : 0));
+  p.slots = 256 * 8;
+  return p;
+}
+
+size_t search_workspace_bytes(const DeviceIndex& ix, const SearchArgs& a) {
+  Plan p = make_plan(ix, a);
+  size_t need = 256;                                   // counter + status
+  need += (size_t)a.nq * p.dcap * 8;                   // dropped lists
+  if (!p.hash_lds) need += ((size_t)std::min<uint64_t>(a.nq, p.slots) << p.bits) * 4;
+  return need;
+}
+
+template <int DT, int METRIC, int LPC, bool NCH1>
+static hipError_t launch_variant(const BSParams& P, const Plan& p, hipStream_t stream) {
+  if (p.hash_lds) {
+    auto kern = beam_search_kernel<DT, METRIC, LPC, NCH1, true>;
+    if (p.lds_bytes > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+    hipLaunchKernelGGL(kern, dim3(P.nq), dim3(PANN_WAVE), p.lds_bytes, stream, P);
+  } else {
+    auto kern = beam_search_kernel<DT, METRIC, LPC, NCH1, false>;
+    if (p.lds_bytes > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(P.nq, p.slots);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(PANN_WAVE), p.lds_bytes, stream, P);
+  }
+  return hipGetLastError();
+}
+
+template <int DT, int METRIC>
+static hipError_t launch_layout(const DeviceIndex& ix, const BSParams& P, const Plan& p, hipStream_t s) {
+  if (ix.nch == 1) {
+    if (ix.lpc == 8) return launch_variant<DT, METRIC, 8, true>(P, p, s);
+    if (ix.lpc == 16) return launch_variant<DT, METRIC, 16, true>(P, p, s);
+    if (ix.lpc == 32) return launch_variant<DT, METRIC, 32, true>(P, p, s);
+  }
+  if (ix.lpc == 4) return launch_variant<DT, METRIC, 4, false>(P, p, s);
+  if (ix.lpc == 16) return launch_variant<DT, METRIC, 16, false>(P, p, s);
+  return hipErrorInvalidValue;
+}
+
+int launch_beam_search(const DeviceIndex& ix, const SearchArgs& a, void* ws, size_t ws_bytes,
+                       hipStream_t stream) {
+  if (a.nq == 0) return PANN_OK;
+  if (a.nq > 0xFFFFFFF0ull) { set_error("pann_batch_search: nq too large"); return PANN_ERR_BAD_ARG; }
+  if (a.beam <= 0 || a.beam > 65536) { set_error("pann_batch_search: beam out of range [1,65536]"); return PANN_ERR_BAD_ARG; }
+  if (a.nstarts == 0) {  // beamSearch.h:38-41
+    set_error("beam search expects at least one start point"); return PANN_ERR_BAD_ARG;
+  }
+  if ((int64_t)a.nstarts > a.beam) { set_error("pann_batch_search: more start points than beam"); return PANN_ERR_BAD_ARG; }
+  if (a.out.out_k > (uint64_t)a.beam) {  // beamSearch.h:368-372
+    set_error("Error: beam search parameter Q same size or smaller than k"); return PANN_ERR_BAD_ARG;
+  }
+  if ((a.queries == nullptr) == (a.query_ids == nullptr)) {
+    set_error("pann_batch_search: exactly one of queries / query_ids must be given"); return PANN_ERR_BAD_ARG;
+  }
+  Plan p = make_plan(ix, a);
+  if (p.lds_bytes > 160 * 1024) { set_error("pann_batch_search: beam/degree too large for LDS state"); return PANN_ERR_UNSUPPORTED; }
+  if (search_workspace_bytes(ix, a) > ws_bytes) { set_error("pann_batch_search: workspace too small"); return PANN_ERR_BAD_ARG; }
+
+  BSParams P;
+  P.points = ix.points; P.pstride = ix.pstride; P.dbytes = ix.dbytes; P.nch = ix.nch;
+  P.graph = ix.graph; P.gstride = ix.gstride; P.max_deg = ix.max_deg;
+  P.queries = a.queries; P.qstride = a.qstride; P.query_ids = a.query_ids;
+  P.starts = a.starts; P.nstarts = a.nstarts; P.nq = (uint32_t)a.nq;
+  P.k = (uint32_t)std::max<int64_t>(a.k, 0); P.beam = (uint32_t)a.beam;
+  P.limit = (uint32_t)std::min<int64_t>(std::max<int64_t>(a.limit, 0), 0xFFFFFFFFll);
+  P.degree_limit = p.deg_eff; P.cut = a.cut;
+  P.skip_enabled = (a.limit >= 2 * a.beam) ? 1u : 0u;
+  P.cut_enabled = (a.k > 0 && ix.metric == PANN_L2) ? 1u : 0u;
+  P.bits = p.bits; P.bcap = p.bcap; P.ccap = p.ccap;
+  uint8_t* w = (uint8_t*)ws;
+  P.work_counter = (uint32_t*)w; P.status = (uint32_t*)(w + 64);
+  P.dropped = (uint64_t*)(w + 256); P.dcap = p.dcap;
+  P.hash_global = p.hash_lds ? nullptr : (uint32_t*)(w + 256 + (size_t)a.nq * p.dcap * 8);
+  P.out = a.out;
+  PANN_HIP(hipMemsetAsync(w, 0, 256, stream));
+
+  hipError_t e = hipErrorInvalidValue;
+#define PANN_DISPATCH(DT, MT) if (ix.dtype == DT && ix.metric == MT) e = launch_layout<DT, MT>(ix, P, p, stream);
+  PANN_DISPATCH(PANN_U8, PANN_L2) PANN_DISPATCH(PANN_U8, PANN_MIPS)
+  PANN_DISPATCH(PANN_I8, PANN_L2) PANN_DISPATCH(PANN_I8, PANN_MIPS)
+  PANN_DISPATCH(PANN_F32, PANN_L2) PANN_DISPATCH(PANN_F32, PANN_MIPS)
+  PANN_DISPATCH(PANN_F16, PANN_L2) PANN_DISPATCH(PANN_F16, PANN_MIPS)
+#undef PANN_DISPATCH
+  if (e != hipSuccess) return hip_fail(e, "beam_search_kernel launch");
+  return PANN_OK;
+}
+
+}  // namespace pann

@@ -1,0 +1,68 @@
+// pann_internal.h -- private declarations shared by the HIP translation units of libpann.so.
+// Target: gfx950 (MI355X, CDNA4) only.  64-lane wavefronts are assumed everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/pann.h"
+
+namespace pann {
+
+constexpr uint32_t SENTINEL = 0xFFFFFFFFu;  // empty adjacency slot on the device / empty filter slot
+
+// ---- device-side layout of one index (DESIGN.md "Data layout in HBM") ----
+//  points: n rows, row stride pstride = nch * lpc * 16 bytes (>= d*esize), zero padded
+//  graph : n rows of gstride uint32 (gstride = max_deg rounded up to 16), neighbours packed at the
+//          front, unused slots = SENTINEL; the degree is not stored (it is the count of
+//          non-sentinel slots), so a row of max_deg 64 is exactly one aligned 256-byte read.
+struct DeviceIndex {
+  uint8_t* points = nullptr;
+  uint32_t* graph = nullptr;
+  uint64_t n = 0;
+  uint32_t d = 0;
+  int dtype = 0, metric = 0;
+  uint32_t esize = 0;    // bytes per element
+  uint32_t dbytes = 0;   // d * esize
+  uint32_t pstride = 0;  // device row stride in bytes
+  uint32_t lpc = 0;      // lanes per candidate in the gather-distance loops (4,8,16,32)
+  uint32_t nch = 0;      // 16-byte chunks per lane: pstride = nch*lpc*16
+  uint32_t max_deg = 0;
+  uint32_t gstride = 0;  // uint32 per graph row on the device
+};
+
+struct SearchArgs {  // one batched beam search, everything device resident
+  const uint8_t* queries; uint64_t qstride;  // external queries (or null)
+  const uint32_t* query_ids;                 // base-point queries (or null)
+  uint64_t nq;
+  const uint32_t* starts; uint32_t nstarts;
+  int64_t k, beam, limit, degree_limit; double cut;
+  pann_search_out out;
+};
+
+// per-handle scratch that the search kernels need (grown on demand, never shrunk)
+struct Workspace {
+  void* buf = nullptr; size_t bytes = 0;
+  int ensure(size_t need);
+  void release();
+};
+
+void set_error(const std::string& s);
+int hip_fail(hipError_t e, const char* what);
+#define PANN_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return pann::hip_fail(e_, #call); } while (0)
+
+// beam_search.hip
+size_t search_workspace_bytes(const DeviceIndex& ix, const SearchArgs& a);
+int launch_beam_search(const DeviceIndex& ix, const SearchArgs& a, void* ws, size_t ws_bytes,
+                       hipStream_t stream);
+void choose_point_layout(uint32_t dbytes, uint32_t* lpc, uint32_t* nch);
+
+// prune.hip
+int launch_robust_prune(const DeviceIndex& ix, const uint32_t* d_owners, uint64_t m,
+                        const uint32_t* d_cand_ids, const float* d_cand_dists,
+                        const uint64_t* d_cand_offsets, uint32_t max_cand, double alpha, uint32_t R,
+                        int add_out_nbrs, uint32_t* d_out_rows /* m x gstride-like (R+1) */,
+                        uint32_t* d_out_dist_cmps, void* ws, size_t ws_bytes, hipStream_t stream);
+size_t prune_workspace_bytes(uint64_t m, uint32_t max_cand);
+
+}  // namespace pann

@@ -1,0 +1,126 @@
+"""DeviceIndex: thin Python owner of a pann_index handle (device mirror of PointRange + Graph).
+
+Mirrors what python/graph_index.cpp:82-118 holds (points + graph) and the batched seam of
+:192-216; numpy arrays in, numpy arrays out.  Every method goes through the C-ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import (PANN_F16, PANN_F32, PANN_I8, PANN_L2, PANN_MIPS, PANN_U8, BuildStats, QueryParams, SearchOut,
+                    check)
+
+_DT = {np.dtype(np.uint8): PANN_U8, np.dtype(np.int8): PANN_I8, np.dtype(np.float32): PANN_F32,
+       np.dtype(np.float16): PANN_F16}
+
+
+def dtype_code(dt):
+    return _DT[np.dtype(dt)]
+
+
+def _metric_code(metric):
+    if metric in (PANN_L2, PANN_MIPS):
+        return metric
+    m = str(metric).lower()
+    if m in ("euclidian", "euclidean", "l2"):
+        return PANN_L2
+    if m in ("mips", "ip"):
+        return PANN_MIPS
+    raise ValueError(f"unknown metric {metric!r}")
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def host_graph(n, max_deg):
+    """An empty graph slab in the reference layout (graph.h:134-141): n x (max_deg+1), slot 0 = degree."""
+    return np.zeros((n, max_deg + 1), dtype=np.uint32)
+
+
+class DeviceIndex:
+    def __init__(self, points, graph=None, max_degree=None, metric="Euclidian", device=0):
+        lib = _capi.load()
+        points = np.ascontiguousarray(points)
+        if points.ndim != 2 or points.dtype not in _DT:
+            raise ValueError("points must be a 2-D uint8/int8/float32/float16 array")
+        n, d = points.shape
+        if graph is not None:
+            graph = np.ascontiguousarray(graph, dtype=np.uint32)
+            if graph.ndim != 2 or graph.shape[0] != n:
+                raise ValueError("graph must be n x (max_deg+1) uint32 (reference layout)")
+            max_degree = graph.shape[1] - 1
+        if max_degree is None:
+            raise ValueError("give a graph or max_degree")
+        self.n, self.d, self.max_degree = n, d, int(max_degree)
+        self.dtype, self.metric = points.dtype, _metric_code(metric)
+        h = C.c_void_p()
+        check(lib.pann_index_create(C.byref(h), _ptr(points), n, d, _DT[points.dtype], points.strides[0],
+                                    self.metric, _ptr(graph), self.max_degree, device))
+        self._h, self._lib = h, lib
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pann_index_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def handle(self):
+        return self._h
+
+    # ---- graph ----
+    def set_graph(self, graph):
+        graph = np.ascontiguousarray(graph, dtype=np.uint32)
+        assert graph.shape == (self.n, self.max_degree + 1)
+        check(self._lib.pann_index_set_graph(self._h, _ptr(graph)))
+
+    def update_rows(self, row_ids, rows):
+        row_ids = np.ascontiguousarray(row_ids, dtype=np.uint32)
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        assert rows.shape == (len(row_ids), self.max_degree + 1)
+        check(self._lib.pann_index_update_rows(self._h, _ptr(row_ids), _ptr(rows), len(row_ids)))
+
+    def get_graph(self):
+        g = np.empty((self.n, self.max_degree + 1), dtype=np.uint32)
+        check(self._lib.pann_index_get_graph(self._h, _ptr(g)))
+        return g
+
+    # ---- batched beam search: the searchAll / qsearchAll seam (beamSearch.h:374,556) ----
+    def batch_search(self, queries=None, k=10, beam=64, cut=1.35, limit=None, degree_limit=None, starts=(0,),
+                     query_ids=None, out_k=None, visited_cap=0, want_dists=True):
+        nq = len(queries) if queries is not None else len(query_ids)
+        qp = QueryParams(k=k, beam=beam, cut=cut, limit=self.n if limit is None else limit,
+                         degree_limit=self.max_degree if degree_limit is None else degree_limit,
+                         rerank_factor=100, pad=1.0)
+        out_k = k if out_k is None else out_k
+        res = {
+            "ids": np.empty((nq, out_k), dtype=np.uint32),
+            "dists": np.empty((nq, out_k), dtype=np.float32) if want_dists else None,
+            "frontier_size": np.empty(nq, dtype=np.uint32),
+            "visited_count": np.empty(nq, dtype=np.uint32),
+            "dist_cmps": np.empty(nq, dtype=np.uint32),
+            "degree_sum": np.empty(nq, dtype=np.uint32),
+            "visited_ids": np.empty((nq, visited_cap), dtype=np.uint32) if visited_cap else None,
+            "visited_dists": np.empty((nq, visited_cap), dtype=np.float32) if visited_cap else None,
+        }
+        out = SearchOut(ids=_ptr(res["ids"]), dists=_ptr(res["dists"]), out_k=out_k,
+                        frontier_size=_ptr(res["frontier_size"]), visited_count=_ptr(res["visited_count"]),
+                        dist_cmps=_ptr(res["dist_cmps"]), degree_sum=_ptr(res["degree_sum"]),
+                        visited_ids=_ptr(res["visited_ids"]), visited_dists=_ptr(res["visited_dists"]),
+                        visited_cap=visited_cap)
+        starts = np.ascontiguousarray(starts, dtype=np.uint32)
+        q = qid = None
+        stride = 0
+        if queries is not None:
+            q = np.ascontiguousarray(queries)
+            if q.dtype != self.dtype or q.ndim != 2 or q.shape[1] != self.d:
+                raise ValueError("queries must be nq x d of the index dtype")
+            stride = q.strides[0]
+        else:
+            qid = np.ascontiguousarray(query_ids, dtype=np.uint32)
+        check(self._lib.pann_batch_search(self._h, _ptr(q), _ptr(qid), nq, stride, _ptr(starts), len(starts),
+                                          C.byref(qp), C.byref(out)))
+        return res

@@ -1,0 +1,161 @@
+"""GPU parity of the batched beam search (C-ABI pann_batch_search -> HIP kernel) against the CPU
+oracle on identical seeded inputs.  Integer / integer-valued data: ids, dists, visited, dist_cmps
+must match BIT FOR BIT (north_star: "integer top-k indices bit-exact at fixed beam width")."""
+import numpy as np
+import pytest
+
+from parlayann_amd import DeviceIndex, datasets
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(n, d, dtype, seed):
+    if dtype == np.int8:
+        x = datasets.sift_like(n, d, seed=seed, dtype=np.float32)
+        return (x - 128.0).clip(-127, 127).astype(np.int8)
+    return datasets.sift_like(n, d, seed=seed, dtype=dtype)
+
+
+_cache = {}
+
+
+def _setup(oracle, n, d, dtype, metric, R=32, L=64, nq=300):
+    key = (n, d, np.dtype(dtype).name, metric, R, L, nq)
+    if key not in _cache:
+        X = _data(n, d, dtype, 1234)
+        Q = _data(nq, d, dtype, 4321)
+        G, _ = oracle.vamana_build(X, R=R, L=L, alpha=1.2 if metric == "l2" else 1.0, num_passes=1, seed=7,
+                                   metric=metric)
+        _cache[key] = (X, Q, G)
+    return _cache[key]
+
+
+def _compare(o, g, visited=False):
+    for f in ("frontier_size", "visited_count", "dist_cmps", "degree_sum"):
+        np.testing.assert_array_equal(o[f], g[f], err_msg=f)
+    np.testing.assert_array_equal(o["ids"], g["ids"])
+    np.testing.assert_array_equal(o["dists"].view(np.uint32), g["dists"].view(np.uint32))
+    if visited:
+        for i in range(len(o["ids"])):
+            nv = o["visited_count"][i]
+            np.testing.assert_array_equal(o["visit_order_ids"][i, :nv], g["visited_ids"][i, :nv])
+            # reference order (sorted by (dist,id)) is recovered by sorting the device's visit-order list
+            order = np.lexsort((g["visited_ids"][i, :nv], g["visited_dists"][i, :nv]))
+            np.testing.assert_array_equal(o["visited_ids"][i, :nv], g["visited_ids"][i, :nv][order])
+            np.testing.assert_array_equal(o["visited_dists"][i, :nv], g["visited_dists"][i, :nv][order])
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.int8, np.float32, np.float16])
+@pytest.mark.parametrize("metric", ["l2", "mips"])
+def test_search_dtypes_d128(oracle, dtype, metric):
+    X, Q, G = _setup(oracle, 6000, 128, dtype, metric)
+    ix = DeviceIndex(X, G, metric=metric)
+    for beam, k in ((64, 10), (32, 10), (10, 10)):
+        o = oracle.batch_search(X, G, queries=Q, k=k, beam=beam, cut=1.35, metric=metric)
+        g = ix.batch_search(Q, k=k, beam=beam, cut=1.35)
+        _compare(o, g)
+    ix.close()
+
+
+@pytest.mark.parametrize("beam", [1, 7, 16, 64, 100, 128, 200, 300])
+def test_search_beams_u8(oracle, beam):
+    X, Q, G = _setup(oracle, 8000, 128, np.uint8, "l2")
+    ix = DeviceIndex(X, G)
+    k = min(10, beam)
+    o = oracle.batch_search(X, G, queries=Q, k=k, beam=beam, cut=1.35, out_k=beam, visited_cap=2048)
+    g = ix.batch_search(Q, k=k, beam=beam, cut=1.35, out_k=beam, visited_cap=2048)
+    assert o["rc"] == 0
+    _compare(o, g, visited=True)
+    ix.close()
+
+
+@pytest.mark.parametrize("k,cut,limit,dl", [(0, 0.0, None, None), (10, 0.0, None, None), (10, 1.35, 20, None),
+                                            (10, 1.35, 1000, 16), (10, 1.1, 100, None), (5, 2.0, None, 8),
+                                            (10, 1.35, 0, None), (10, 1.35, 127, None), (10, 1.35, 128, None)])
+def test_search_params_f16(oracle, k, cut, limit, dl):
+    X, Q, G = _setup(oracle, 8000, 128, np.float16, "l2")
+    ix = DeviceIndex(X, G)
+    o = oracle.batch_search(X, G, queries=Q, k=k, beam=64, cut=cut, limit=limit, degree_limit=dl, out_k=64,
+                            visited_cap=1024)
+    g = ix.batch_search(Q, k=k, beam=64, cut=cut, limit=limit, degree_limit=dl, out_k=64, visited_cap=1024)
+    _compare(o, g, visited=True)
+    ix.close()
+
+
+@pytest.mark.parametrize("d,dtype", [(96, np.float32), (100, np.uint8), (200, np.int8), (200, np.float32),
+                                     (32, np.uint8), (17, np.float32), (960, np.float32), (48, np.float16)])
+def test_search_dims(oracle, d, dtype):
+    metric = "mips" if d == 200 else "l2"
+    X, Q, G = _setup(oracle, 4000, d, dtype, metric, nq=150)
+    ix = DeviceIndex(X, G, metric=metric)
+    o = oracle.batch_search(X, G, queries=Q, k=10, beam=48, cut=1.35, metric=metric, out_k=48)
+    g = ix.batch_search(Q, k=10, beam=48, cut=1.35, out_k=48)
+    _compare(o, g)
+    ix.close()
+
+
+def test_search_build_mode_query_ids(oracle):
+    """beam_search_rerank__ as batch_insert calls it (vamana/index.h:250-259): k=0, L, cut 0, limit n,
+    the query is a base point and is skipped as a neighbour (same_as, beamSearch.h:133)."""
+    X, Q, G = _setup(oracle, 8000, 128, np.uint8, "l2")
+    ix = DeviceIndex(X, G)
+    qids = np.random.default_rng(5).integers(0, len(X), size=400).astype(np.uint32)
+    for L in (64, 128):
+        o = oracle.batch_search(X, G, query_ids=qids, k=0, beam=L, cut=0.0, out_k=L, visited_cap=1024)
+        g = ix.batch_search(query_ids=qids, k=0, beam=L, cut=0.0, out_k=L, visited_cap=1024)
+        _compare(o, g, visited=True)
+    ix.close()
+
+
+def test_search_multiple_starts_and_strided_queries(oracle):
+    X, Q, G = _setup(oracle, 8000, 128, np.uint8, "l2")
+    ix = DeviceIndex(X, G)
+    starts = np.array([0, 17, 4000, 7999, 5, 123], dtype=np.uint32)
+    Qwide = np.zeros((len(Q), 200), dtype=np.uint8)
+    Qwide[:, :128] = Q
+    Qs = Qwide[:, :128]  # row stride 200 bytes: unaligned rows
+    o = oracle.batch_search(X, G, queries=Q, k=10, beam=64, starts=starts)
+    from parlayann_amd._capi import QueryParams, SearchOut, check
+    import ctypes as C
+    nq = len(Q)
+    ids = np.empty((nq, 10), np.uint32); dists = np.empty((nq, 10), np.float32)
+    vc = np.empty(nq, np.uint32); dc = np.empty(nq, np.uint32)
+    out = SearchOut(ids=ids.ctypes.data, dists=dists.ctypes.data, out_k=10, visited_count=vc.ctypes.data,
+                    dist_cmps=dc.ctypes.data)
+    qp = QueryParams(k=10, beam=64, cut=1.35, limit=len(X), degree_limit=32, rerank_factor=100, pad=1.0)
+    check(ix._lib.pann_batch_search(ix.handle, Qs.ctypes.data, None, nq, 200, starts.ctypes.data, len(starts),
+                                    C.byref(qp), C.byref(out)))
+    np.testing.assert_array_equal(o["ids"], ids)
+    np.testing.assert_array_equal(o["dists"], dists)
+    np.testing.assert_array_equal(o["visited_count"], vc)
+    np.testing.assert_array_equal(o["dist_cmps"], dc)
+    ix.close()
+
+
+def test_search_errors(oracle):
+    from parlayann_amd import PannError
+    X, Q, G = _setup(oracle, 8000, 128, np.uint8, "l2")
+    ix = DeviceIndex(X, G)
+    with pytest.raises(PannError):   # k > beam: beamSearch.h:368-372
+        ix.batch_search(Q, k=20, beam=10)
+    with pytest.raises(PannError):   # no start point: beamSearch.h:38-41
+        ix.batch_search(Q, k=10, beam=64, starts=())
+    with pytest.raises(PannError):   # visited list does not fit
+        ix.batch_search(Q, k=10, beam=64, visited_cap=4)
+    ix.close()
+
+
+def test_graph_roundtrip_and_update_rows(oracle):
+    X, Q, G = _setup(oracle, 8000, 128, np.uint8, "l2")
+    ix = DeviceIndex(X, G)
+    np.testing.assert_array_equal(ix.get_graph(), G)
+    rows = np.zeros((3, G.shape[1]), np.uint32)
+    rows[0, :4] = [3, 10, 11, 12]; rows[1, 0] = 0; rows[2, :2] = [1, 7999]
+    ids = np.array([5, 100, 7999], np.uint32)
+    ix.update_rows(ids, rows)
+    G2 = G.copy(); G2[ids] = rows
+    np.testing.assert_array_equal(ix.get_graph(), G2)
+    o = oracle.batch_search(X, G2, queries=Q, k=10, beam=64)
+    g = ix.batch_search(Q, k=10, beam=64)
+    _compare(o, g)
+    ix.close()
