@@ -53,7 +53,8 @@ struct pann_index {
   DeviceIndex ix;
   int device = 0;
   hipStream_t stream = nullptr;
-  Workspace ws;          // kernel scratch
+  Workspace ws, ws2, ws3;   // kernel scratch (search / prune / re-prune)
+  uint32_t vcap = 0;        // visited-list capacity used by the builder (grows on overflow)
   DevBuf stage[12];      // staging for host-pointer calls
   std::vector<uint32_t> hrow;  // host scratch
 };
@@ -210,7 +211,7 @@ void pann_index_destroy(pann_index* idx) {
   if (idx->stream) (void)hipStreamSynchronize(idx->stream);
   if (idx->ix.points) (void)hipFree(idx->ix.points);
   if (idx->ix.graph) (void)hipFree(idx->ix.graph);
-  idx->ws.release();
+  idx->ws.release(); idx->ws2.release(); idx->ws3.release();
   for (auto& s : idx->stage) s.release();
   if (idx->stream) (void)hipStreamDestroy(idx->stream);
   delete idx;
@@ -359,6 +360,99 @@ int pann_batch_search(pann_index* idx, const void* queries, const uint32_t* quer
   PANN_HIP(hipStreamSynchronize(st));
   if (status & 1u) { set_error("pann_batch_search: visited list longer than visited_cap"); return PANN_ERR_OVERFLOW; }
   if (status & 2u) { set_error("pann_batch_search: internal dropped-list overflow"); return PANN_ERR_OVERFLOW; }
+  return PANN_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// robustPrune / Vamana build
+// ---------------------------------------------------------------------------------------------
+
+int pann_robust_prune_batch(pann_index* idx, const uint32_t* owners, uint64_t m, const uint32_t* cand_ids,
+                            const float* cand_dists, const uint64_t* cand_offsets, double alpha, uint32_t R,
+                            int add_out_nbrs, uint32_t* out_rows, uint32_t* out_dist_cmps) {
+  if (int rc = check_idx(idx, "pann_robust_prune_batch")) return rc;
+  if (m && (!owners || !cand_offsets || !out_rows)) { set_error("pann_robust_prune_batch: null argument"); return PANN_ERR_BAD_ARG; }
+  if (m && cand_offsets[m] && !cand_ids) { set_error("pann_robust_prune_batch: null candidate ids"); return PANN_ERR_BAD_ARG; }
+  DeviceGuard g(idx->device);
+  return robust_prune_batch_host(idx->ix, idx->ws2, idx->stream, owners, m, cand_ids, cand_dists, cand_offsets,
+                                 alpha, R, add_out_nbrs, out_rows, out_dist_cmps);
+}
+
+static uint32_t default_vcap(uint32_t L) { return std::max<uint32_t>(2 * L, 128); }
+
+int pann_vamana_insert_batch(pann_index* idx, const uint32_t* batch_ids, uint64_t m, uint32_t start, uint32_t R,
+                             uint32_t L, double alpha, pann_build_stats* stats) {
+  if (int rc = check_idx(idx, "pann_vamana_insert_batch")) return rc;
+  if (m == 0) return PANN_OK;
+  if (!batch_ids) { set_error("pann_vamana_insert_batch: null batch"); return PANN_ERR_BAD_ARG; }
+  if (L == 0 || L > 65536) { set_error("pann_vamana_insert_batch: L out of range"); return PANN_ERR_BAD_ARG; }
+  if (start >= idx->ix.n) { set_error("pann_vamana_insert_batch: start out of range"); return PANN_ERR_BAD_ARG; }
+  for (uint64_t i = 0; i < m; i++)
+    if (batch_ids[i] >= idx->ix.n) {  // vamana/index.h:193-198
+      set_error("ERROR: invalid point " + std::to_string(batch_ids[i]) + " given to batch_insert"); return PANN_ERR_BAD_ARG;
+    }
+  DeviceGuard g(idx->device);
+  if (int rc = idx->stage[2].ensure(m * 4)) return rc;
+  PANN_HIP(hipMemcpyAsync(idx->stage[2].p, batch_ids, m * 4, hipMemcpyHostToDevice, idx->stream));
+  if (idx->vcap < default_vcap(L)) idx->vcap = default_vcap(L);
+  return insert_batch_dev(idx->ix, idx->ws2, idx->ws3, idx->ws, idx->stream, idx->stage[2].as<uint32_t>(), (uint32_t)m,
+                          start, R, L, alpha, &idx->vcap, stats);
+}
+
+// the insertion order of this build: Fisher-Yates driven by splitmix64(seed) (DESIGN.md "Build
+// determinism"; parlay::random_permutation, vamana/index.h:212, is not reproducible offline)
+static void build_permutation(uint64_t m, uint64_t seed, std::vector<uint32_t>& out) {
+  out.resize(m);
+  for (uint64_t i = 0; i < m; i++) out[i] = (uint32_t)i;
+  uint64_t s = seed;
+  auto next = [&]() {
+    uint64_t z = (s += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+  };
+  for (uint64_t i = m; i > 1; i--) std::swap(out[i - 1], out[next() % i]);
+}
+
+int pann_vamana_build(pann_index* idx, uint32_t R, uint32_t L, double alpha, int num_passes, uint64_t seed,
+                      int sort_neighbors, pann_build_stats* stats) {
+  if (int rc = check_idx(idx, "pann_vamana_build")) return rc;
+  if (L == 0 || L > 65536 || num_passes < 1) { set_error("pann_vamana_build: bad L / num_passes"); return PANN_ERR_BAD_ARG; }
+  DeviceGuard g(idx->device);
+  const uint64_t n = idx->ix.n;
+  std::vector<uint32_t> perm;
+  build_permutation(n, seed, perm);
+  if (int rc = idx->stage[2].ensure(n * 4)) return rc;
+  PANN_HIP(hipMemcpyAsync(idx->stage[2].p, perm.data(), n * 4, hipMemcpyHostToDevice, idx->stream));
+  PANN_HIP(hipStreamSynchronize(idx->stream));
+  const uint32_t* d_perm = idx->stage[2].as<uint32_t>();
+  if (idx->vcap < default_vcap(L)) idx->vcap = default_vcap(L);
+  // vamana/index.h:206-209
+  size_t max_batch = std::min<size_t>((size_t)(0.02 * (double)(float)n), 1000000ul);
+  if (max_batch == 0) max_batch = n;
+  for (int pass = 0; pass < num_passes; pass++) {
+    const double a = (pass == num_passes - 1) ? alpha : 1.0;   // :173-178
+    size_t count = 0, inc = 0;
+    while (count < n) {                                         // :223-234
+      size_t floor, ceiling;
+      if (std::pow(2.0, (double)inc) <= (double)max_batch) {
+        floor = (size_t)std::pow(2.0, (double)inc) - 1;
+        ceiling = std::min((size_t)std::pow(2.0, (double)(inc + 1)) - 1, (size_t)n);
+        count = ceiling;
+      } else {
+        floor = count;
+        ceiling = std::min(count + max_batch, (size_t)n);
+        count += max_batch;
+      }
+      if (int rc = insert_batch_dev(idx->ix, idx->ws2, idx->ws3, idx->ws, idx->stream, d_perm + floor,
+                                    (uint32_t)(ceiling - floor), 0u /* set_start(): vertex 0, :148 */, R, L, a,
+                                    &idx->vcap, stats))
+        return rc;
+      inc++;
+    }
+  }
+  if (sort_neighbors) return sort_neighbors_dev(idx->ix, idx->stream);   // :180-185
   return PANN_OK;
 }
 

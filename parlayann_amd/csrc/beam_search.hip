@@ -42,10 +42,6 @@ struct BSParams {
   pann_search_out out;
 };
 
-__device__ __forceinline__ uint32_t lanes_below(uint64_t m, int lane) {
-  return __popcll(m & ((1ull << lane) - 1ull));
-}
-
 template <bool HASH_LDS>
 __device__ __forceinline__ uint32_t hload(const uint32_t* H, uint32_t s) {
   if constexpr (HASH_LDS) return H[s];
@@ -107,61 +103,21 @@ __device__ __forceinline__ bool filter_update(uint32_t* H, uint32_t hmask, bool 
   return seen;
 }
 
-// Distances from the query (registers qreg / LDS qlds) to the m ids in Pl[0..m); survivors of
-// `dist < cutoff` (:157) are appended to C.  LPC lanes share one candidate: each reads 16 B per
-// chunk, so one load instruction fetches 64/LPC complete row segments.
+// Distances from the query to the m ids in Pl[0..m); survivors of `dist < cutoff` (:157) are
+// appended to C in row order.
 template <int DT, int METRIC, int LPC, bool NCH1, int U>
 __device__ __forceinline__ uint32_t gather_distances(const BSParams& P, const uint4& qreg,
                                                      const uint4* qlds, const uint32_t* Pl, uint32_t m,
                                                      uint32_t cutoff_ord, uint64_t* C, uint32_t c, int lane) {
-  using acc_t = typename AccT<DT>::type;
-  constexpr int G = PANN_WAVE / LPC;
-  const int grp = lane / LPC, sub = lane % LPC;
-  for (uint32_t s0 = 0; s0 < m; s0 += G * U) {
-    acc_t acc[U];
-    uint32_t ids[U];
-    if constexpr (NCH1) {
-      uint4 v[U];
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const uint32_t ci = s0 + u * G + grp;
-        ids[u] = ci < m ? Pl[ci] : SENTINEL;
-        v[u] = make_uint4(0, 0, 0, 0);
-        if (ci < m) v[u] = *reinterpret_cast<const uint4*>(P.points + (uint64_t)ids[u] * P.pstride + sub * 16);
-      }
-#pragma unroll
-      for (int u = 0; u < U; u++) { acc[u] = 0; dist_accum<DT, METRIC>(acc[u], v[u], qreg); }
-    } else {
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const uint32_t ci = s0 + u * G + grp;
-        ids[u] = ci < m ? Pl[ci] : SENTINEL;
-        acc[u] = 0;
-      }
-      for (uint32_t ch = 0; ch < P.nch; ch++) {
-        uint4 v[U];
-        const uint4 qv = qlds[ch * LPC + sub];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          v[u] = make_uint4(0, 0, 0, 0);
-          if (ids[u] != SENTINEL)
-            v[u] = *reinterpret_cast<const uint4*>(P.points + (uint64_t)ids[u] * P.pstride + (ch * LPC + sub) * 16);
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) dist_accum<DT, METRIC>(acc[u], v[u], qv);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const acc_t tot = group_sum<LPC>(acc[u]);
-      const float dist = dist_finish<DT, METRIC>(tot);
+  const PointsView PV{P.points, P.pstride, P.nch};
+  gather_tile<DT, METRIC, LPC, NCH1, U>(PV, qreg, qlds, Pl, m, lane,
+    [&](bool has, uint32_t, uint32_t id, float dist) {
       const uint32_t ord = f2ord(dist);
-      const bool pass = (sub == 0) && (ids[u] != SENTINEL) && (ord < cutoff_ord);
+      const bool pass = has && (ord < cutoff_ord);
       const uint64_t pm = __ballot(pass);
-      if (pass) C[c + lanes_below(pm, lane)] = ((uint64_t)ord << 32) | ids[u];
+      if (pass) C[c + lanes_below(pm, lane)] = ((uint64_t)ord << 32) | id;
       c += __popcll(pm);
-    }
-  }
+    });
   return c;
 }
 
@@ -199,30 +155,8 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_kernel(BSParams P) {
     // ---- query vector -> registers (one chunk) or LDS (generic) ----
     const int64_t self = P.query_ids ? (int64_t)P.query_ids[qi] : -1;
     const uint8_t* qrow = P.query_ids ? P.points + (uint64_t)self * P.pstride : P.queries + (uint64_t)qi * P.qstride;
-    const bool qaligned = ((reinterpret_cast<uintptr_t>(qrow) & 15) == 0);
-    const uint32_t qvalid = P.dbytes;
     uint4 qreg = make_uint4(0, 0, 0, 0);
-    const int sub = lane % LPC;
-    if constexpr (NCH1) {
-      qreg = load16_guarded(qrow, sub * 16, qaligned ? qvalid : 0u);
-      if (!qaligned) {
-        uint8_t tmp[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) tmp[i] = (sub * 16 + i < (int)qvalid) ? qrow[sub * 16 + i] : (uint8_t)0;
-        __builtin_memcpy(&qreg, tmp, 16);
-      }
-    } else {
-      for (uint32_t j = lane; j < P.nch * LPC; j += PANN_WAVE) {
-        uint4 v = load16_guarded(qrow, j * 16, qaligned ? qvalid : 0u);
-        if (!qaligned) {
-          uint8_t tmp[16];
-#pragma unroll
-          for (int i = 0; i < 16; i++) tmp[i] = (j * 16 + i < qvalid) ? qrow[j * 16 + i] : (uint8_t)0;
-          __builtin_memcpy(&v, tmp, 16);
-        }
-        qlds[j] = v;
-      }
-    }
+    load_query<LPC, NCH1>(qrow, P.dbytes, P.nch, qreg, qlds, lane);
     hsync<HASH_LDS>();
 
     uint32_t f = 0;        // frontier size

@@ -148,4 +148,105 @@ __device__ __forceinline__ uint4 load16_guarded(const uint8_t* row, uint32_t off
   return v;
 }
 
+// ---- gather-distance tile: distances from ONE query vector (registers qreg when the row is a
+// single chunk, else LDS qlds) to the m ids in Pl[0..m).  LPC lanes share a candidate, each reads
+// 16 B per chunk, so one load instruction covers 64/LPC whole row segments; U candidates-groups
+// are in flight per lane before the first use.  emit(has, ci, id, dist) is called by ALL lanes
+// (uniform control flow); `has` is true on the first lane of each candidate group. ----
+struct PointsView { const uint8_t* points; uint32_t pstride; uint32_t nch; };
+
+template <int DT, int METRIC, int LPC, bool NCH1, int U, typename Emit>
+__device__ __forceinline__ void gather_tile(const PointsView& PV, const uint4& qreg, const uint4* qlds,
+                                            const uint32_t* Pl, uint32_t m, int lane, Emit&& emit) {
+  using acc_t = typename AccT<DT>::type;
+  constexpr int G = PANN_WAVE / LPC;
+  const int grp = lane / LPC, sub = lane % LPC;
+  for (uint32_t s0 = 0; s0 < m; s0 += G * U) {
+    acc_t acc[U];
+    uint32_t ids[U];
+    if constexpr (NCH1) {
+      uint4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t ci = s0 + u * G + grp;
+        ids[u] = ci < m ? Pl[ci] : SENTINEL;
+        v[u] = make_uint4(0, 0, 0, 0);
+        if (ci < m) v[u] = *reinterpret_cast<const uint4*>(PV.points + (uint64_t)ids[u] * PV.pstride + sub * 16);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) { acc[u] = 0; dist_accum<DT, METRIC>(acc[u], v[u], qreg); }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t ci = s0 + u * G + grp;
+        ids[u] = ci < m ? Pl[ci] : SENTINEL;
+        acc[u] = 0;
+      }
+      for (uint32_t ch = 0; ch < PV.nch; ch++) {
+        uint4 v[U];
+        const uint4 qv = qlds[ch * LPC + sub];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          v[u] = make_uint4(0, 0, 0, 0);
+          if (ids[u] != SENTINEL)
+            v[u] = *reinterpret_cast<const uint4*>(PV.points + (uint64_t)ids[u] * PV.pstride + (ch * LPC + sub) * 16);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) dist_accum<DT, METRIC>(acc[u], v[u], qv);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const acc_t tot = group_sum<LPC>(acc[u]);
+      const float dist = dist_finish<DT, METRIC>(tot);
+      emit((sub == 0) && (ids[u] != SENTINEL), s0 + u * G + grp, ids[u], dist);
+    }
+  }
+}
+
+// load one row (device layout, or an external query row of `valid` bytes) as the wave's query:
+// registers when NCH1, else LDS qlds[nch*LPC].  Caller syncs before using qlds.
+template <int LPC, bool NCH1>
+__device__ __forceinline__ void load_query(const uint8_t* qrow, uint32_t valid, uint32_t nch, uint4& qreg,
+                                           uint4* qlds, int lane) {
+  const bool aligned = ((reinterpret_cast<uintptr_t>(qrow) & 15) == 0);
+  auto fetch = [&](uint32_t j) -> uint4 {
+    if (aligned) return load16_guarded(qrow, j * 16, valid);
+    uint8_t tmp[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) tmp[i] = (j * 16 + i < valid) ? qrow[j * 16 + i] : (uint8_t)0;
+    uint4 v; __builtin_memcpy(&v, tmp, 16); return v;
+  };
+  if constexpr (NCH1) {
+    qreg = fetch(lane % LPC);
+  } else {
+    for (uint32_t j = lane; j < nch * LPC; j += PANN_WAVE) qlds[j] = fetch(j);
+  }
+}
+
+__device__ __forceinline__ uint32_t lanes_below(uint64_t m, int lane) {
+  return __popcll(m & ((1ull << lane) - 1ull));
+}
+
+// dispatch helper shared by the launchers: calls F.template run<DT,METRIC,LPC,NCH1>() for the index
+#define PANN_LAYOUT_SWITCH(ix, DT, MT, CALL)                                   \
+  do {                                                                          \
+    if ((ix).nch == 1 && (ix).lpc == 8) { CALL(DT, MT, 8, true); }              \
+    else if ((ix).nch == 1 && (ix).lpc == 16) { CALL(DT, MT, 16, true); }       \
+    else if ((ix).nch == 1 && (ix).lpc == 32) { CALL(DT, MT, 32, true); }       \
+    else if ((ix).lpc == 4) { CALL(DT, MT, 4, false); }                         \
+    else { CALL(DT, MT, 16, false); }                                           \
+  } while (0)
+#define PANN_TYPE_SWITCH(ix, CALL)                                                             \
+  do {                                                                                          \
+    if ((ix).dtype == PANN_U8 && (ix).metric == PANN_L2) PANN_LAYOUT_SWITCH(ix, PANN_U8, PANN_L2, CALL);        \
+    else if ((ix).dtype == PANN_U8 && (ix).metric == PANN_MIPS) PANN_LAYOUT_SWITCH(ix, PANN_U8, PANN_MIPS, CALL);  \
+    else if ((ix).dtype == PANN_I8 && (ix).metric == PANN_L2) PANN_LAYOUT_SWITCH(ix, PANN_I8, PANN_L2, CALL);    \
+    else if ((ix).dtype == PANN_I8 && (ix).metric == PANN_MIPS) PANN_LAYOUT_SWITCH(ix, PANN_I8, PANN_MIPS, CALL);  \
+    else if ((ix).dtype == PANN_F32 && (ix).metric == PANN_L2) PANN_LAYOUT_SWITCH(ix, PANN_F32, PANN_L2, CALL);  \
+    else if ((ix).dtype == PANN_F32 && (ix).metric == PANN_MIPS) PANN_LAYOUT_SWITCH(ix, PANN_F32, PANN_MIPS, CALL); \
+    else if ((ix).dtype == PANN_F16 && (ix).metric == PANN_L2) PANN_LAYOUT_SWITCH(ix, PANN_F16, PANN_L2, CALL);  \
+    else PANN_LAYOUT_SWITCH(ix, PANN_F16, PANN_MIPS, CALL);                                     \
+  } while (0)
+
 }  // namespace pann

@@ -57,12 +57,14 @@ int launch_beam_search(const DeviceIndex& ix, const SearchArgs& a, void* ws, siz
                        hipStream_t stream);
 void choose_point_layout(uint32_t dbytes, uint32_t* lpc, uint32_t* nch);
 
-// prune.hip
-int launch_robust_prune(const DeviceIndex& ix, const uint32_t* d_owners, uint64_t m,
-                        const uint32_t* d_cand_ids, const float* d_cand_dists,
-                        const uint64_t* d_cand_offsets, uint32_t max_cand, double alpha, uint32_t R,
-                        int add_out_nbrs, uint32_t* d_out_rows /* m x gstride-like (R+1) */,
-                        uint32_t* d_out_dist_cmps, void* ws, size_t ws_bytes, hipStream_t stream);
-size_t prune_workspace_bytes(uint64_t m, uint32_t max_cand);
+// vamana_build.hip
+int robust_prune_batch_host(const DeviceIndex& ix, Workspace& ws, hipStream_t st, const uint32_t* owners,
+                            uint64_t m, const uint32_t* cand_ids, const float* cand_dists,
+                            const uint64_t* cand_offsets, double alpha, uint32_t R, int add_out_nbrs,
+                            uint32_t* out_rows, uint32_t* out_dist_cmps);
+int insert_batch_dev(const DeviceIndex& ix, Workspace& ws, Workspace& ws2, Workspace& search_ws, hipStream_t st,
+                     const uint32_t* d_batch, uint32_t m, uint32_t start, uint32_t R, uint32_t L, double alpha,
+                     uint32_t* vcap_io, pann_build_stats* stats);
+int sort_neighbors_dev(const DeviceIndex& ix, hipStream_t st);
 
 }  // namespace pann

@@ -124,3 +124,29 @@ class DeviceIndex:
         check(self._lib.pann_batch_search(self._h, _ptr(q), _ptr(qid), nq, stride, _ptr(starts), len(starts),
                                           C.byref(qp), C.byref(out)))
         return res
+
+    # ---- robustPrune (vamana/index.h:63-137), batched ----
+    def robust_prune_batch(self, owners, cand_ids, cand_offsets, alpha, R, cand_dists=None, add_out_nbrs=True):
+        owners = np.ascontiguousarray(owners, dtype=np.uint32)
+        cand_ids = np.ascontiguousarray(cand_ids, dtype=np.uint32)
+        off = np.ascontiguousarray(cand_offsets, dtype=np.uint64)
+        cd = None if cand_dists is None else np.ascontiguousarray(cand_dists, dtype=np.float32)
+        m = len(owners)
+        rows = np.zeros((m, R + 1), np.uint32)
+        dc = np.zeros(m, np.uint32)
+        check(self._lib.pann_robust_prune_batch(self._h, _ptr(owners), m, _ptr(cand_ids), _ptr(cd), _ptr(off),
+                                                float(alpha), R, 1 if add_out_nbrs else 0, _ptr(rows), _ptr(dc)))
+        return rows, dc
+
+    # ---- Vamana (vamana/index.h:150-316) ----
+    def vamana_insert_batch(self, batch_ids, R, L, alpha, start=0):
+        b = np.ascontiguousarray(batch_ids, dtype=np.uint32)
+        st = BuildStats()
+        check(self._lib.pann_vamana_insert_batch(self._h, _ptr(b), len(b), start, R, L, float(alpha), C.byref(st)))
+        return st
+
+    def vamana_build(self, R, L, alpha, num_passes=1, seed=1, sort_neighbors=True):
+        st = BuildStats()
+        check(self._lib.pann_vamana_build(self._h, R, L, float(alpha), num_passes, seed, 1 if sort_neighbors else 0,
+                                          C.byref(st)))
+        return st

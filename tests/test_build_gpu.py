@@ -1,0 +1,91 @@
+"""GPU parity of robustPrune and the Vamana builder (C-ABI -> HIP) against the CPU oracle.
+The oracle and the product share the insertion permutation and the reverse-edge ordering rule
+(DESIGN.md "Build determinism"), so on integer-valued data the GRAPHS must be identical."""
+import numpy as np
+import pytest
+
+from parlayann_amd import DeviceIndex, datasets
+
+pytestmark = pytest.mark.gpu
+
+
+def _norm(G):
+    """zero the slots beyond each row's degree (their content is unspecified in both layouts)"""
+    G = G.copy()
+    cols = np.arange(G.shape[1] - 1)[None, :]
+    G[:, 1:][cols >= G[:, :1]] = 0
+    return G
+
+
+@pytest.mark.parametrize("dtype,metric,d", [(np.uint8, "l2", 128), (np.float16, "l2", 128), (np.float32, "l2", 96),
+                                            (np.int8, "mips", 200), (np.float32, "mips", 64)])
+def test_robust_prune_batch(oracle, dtype, metric, d):
+    n = 4000
+    X = datasets.sift_like(n, d, seed=1234, dtype=np.float32)
+    X = (X - 128).clip(-127, 127).astype(np.int8) if dtype == np.int8 else X.astype(dtype)
+    G, _ = oracle.vamana_build(X, R=24, L=48, alpha=1.2 if metric == "l2" else 1.0, seed=3, metric=metric,
+                               max_degree=32)
+    rng = np.random.default_rng(0)
+    owners = rng.integers(0, n, 300).astype(np.uint32)
+    cands, dists = [], []
+    for i, p in enumerate(owners):
+        c = rng.choice(n, int(rng.integers(0, 200)), replace=False).astype(np.uint32)
+        if i % 7 == 0 and len(c) > 3:
+            c = np.concatenate([c, c[:3], [p]]).astype(np.uint32)      # duplicates and the owner itself
+        cands.append(c)
+        dists.append(np.array([oracle.distance(X[j], X[p], metric) for j in c], np.float32))
+    off = np.concatenate([[0], np.cumsum([len(c) for c in cands])]).astype(np.uint64)
+    cid = np.concatenate(cands).astype(np.uint32)
+    cd = np.concatenate(dists).astype(np.float32)
+    ix = DeviceIndex(X, G, metric=metric)
+    for alpha, R, add, with_d in ((1.2, 24, True, True), (1.0, 32, True, False), (1.2, 8, False, True),
+                                  (1.35, 32, False, False)):
+        ro, dco = oracle.robust_prune_batch(X, G, owners, cid, cd if with_d else None, off, alpha, R, add=add,
+                                            metric=metric)
+        rg, dcg = ix.robust_prune_batch(owners, cid, off, alpha, R, cand_dists=cd if with_d else None,
+                                        add_out_nbrs=add)
+        np.testing.assert_array_equal(ro, rg)
+        np.testing.assert_array_equal(dco, dcg)
+    ix.close()
+
+
+def test_insert_batch_matches_oracle(oracle):
+    n = 6000
+    X = datasets.sift_like(n, 128, seed=1234, dtype=np.uint8)
+    R, L = 32, 64
+    perm = oracle.permutation(n, 9)
+    Go = np.zeros((n, R + 1), np.uint32)
+    ix = DeviceIndex(X, max_degree=R)
+    lo = 0
+    for sz in (1, 2, 4, 8, 64, 500, 1500, 2000):
+        batch = perm[lo:lo + sz]; lo += sz
+        so = oracle.vamana_insert_batch(X, Go, batch, R, L, 1.2)
+        sg = ix.vamana_insert_batch(batch, R, L, 1.2)
+        np.testing.assert_array_equal(_norm(Go), _norm(ix.get_graph()), err_msg=f"after batch of {sz}")
+        assert int(so[0]) == sg.search_dist_cmps and int(so[1]) == sg.prune_dist_cmps and int(so[2]) == sg.visited_total
+    ix.close()
+
+
+@pytest.mark.parametrize("dtype,metric,d,n,R,L,passes", [
+    (np.uint8, "l2", 128, 10000, 32, 64, 1),
+    (np.float16, "l2", 128, 6000, 64, 128, 2),
+    (np.float32, "l2", 96, 5000, 24, 48, 1),
+    (np.int8, "mips", 200, 5000, 40, 80, 1),
+])
+def test_full_build_identical_graph(oracle, dtype, metric, d, n, R, L, passes):
+    X = datasets.sift_like(n, d, seed=1234, dtype=np.float32)
+    X = (X - 128).clip(-127, 127).astype(np.int8) if dtype == np.int8 else X.astype(dtype)
+    alpha = 1.2 if metric == "l2" else 1.0
+    Go, so = oracle.vamana_build(X, R, L, alpha, num_passes=passes, seed=11, metric=metric)
+    ix = DeviceIndex(X, max_degree=R, metric=metric)
+    sg = ix.vamana_build(R, L, alpha, num_passes=passes, seed=11)
+    Gg = ix.get_graph()
+    np.testing.assert_array_equal(_norm(Go), _norm(Gg))
+    assert int(so[0]) == sg.search_dist_cmps and int(so[1]) == sg.prune_dist_cmps
+    # and the graph is usable: search on it matches the oracle searching the oracle's graph
+    Q = datasets.sift_like(100, d, seed=4321, dtype=np.float32)
+    Q = (Q - 128).clip(-127, 127).astype(np.int8) if dtype == np.int8 else Q.astype(dtype)
+    o = oracle.batch_search(X, Go, queries=Q, k=10, beam=32, metric=metric)
+    g = ix.batch_search(Q, k=10, beam=32)
+    np.testing.assert_array_equal(o["ids"], g["ids"])
+    ix.close()
