@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric: QPS @ recall@10 >= 0.95 on SIFT-1M-shaped data (d=128, beam=64)
+with the achieved fraction of the HBM roofline, 1..8 GPUs (one process per GPU, no collective on
+the data path: queries shard embarrassingly, the index is replicated -- SURVEY.md section 8e).
+
+A "step" = one batched beam search (pann_batch_search_dev) over --nq queries already resident in
+HBM, results left in HBM.  Weak scaling: every rank searches its own --nq queries per step.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--nq", type=int, default=10_000)
+    ap.add_argument("--d", type=int, default=128)
+    ap.add_argument("--beam", type=int, default=64)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--R", type=int, default=64)
+    ap.add_argument("--L", type=int, default=128)
+    ap.add_argument("--alpha", type=float, default=1.15)
+    ap.add_argument("--passes", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from parlayann_amd import DeviceIndex, datasets, _capi
+    from parlayann_amd._capi import QueryParams, SearchOut, check
+    from parlayann_amd.recall import recall_at_k
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible and there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)   # RCCL; used only for barriers + max-over-ranks
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # ---- synthetic SIFT-1M-shaped data: integer-valued in [0,255] (see datasets.sift_like) ----
+    t0 = time.time()
+    Xf = datasets.sift_like(args.n, args.d, seed=1234, dtype=np.float32)      # the reference's float points
+    X = Xf.astype(np.float16)                                                 # "fp32 -> fp16": exact here
+    Q = datasets.sift_like(args.nq, args.d, seed=4321 + rank, dtype=np.float16)
+    log(f"[rank {rank}] data generated in {time.time() - t0:.1f}s")
+
+    # ---- index: replicated on every GPU, built on the device by the product's own builder ----
+    ix = DeviceIndex(X, max_degree=args.R, device=local_rank)
+    t0 = time.time()
+    bst = ix.vamana_build(args.R, args.L, args.alpha, num_passes=args.passes, seed=1, sort_neighbors=True)
+    build_s = time.time() - t0
+    log(f"[rank {rank}] vamana build n={args.n} R={args.R} L={args.L} passes={args.passes}: {build_s:.1f}s "
+        f"(search {bst.t_search_s:.1f}s prune {bst.t_prune_s:.1f}s bidirect {bst.t_bidirect_s:.1f}s "
+        f"reprune {bst.t_reprune_s:.1f}s)")
+
+    # ---- device-resident inputs / outputs ----
+    lib = _capi.load()
+    d_q = torch.from_numpy(Q.view(np.int16)).to(dev)              # raw fp16 bits
+    d_starts = torch.zeros(1, dtype=torch.int32, device=dev)      # start point 0 (check_nn_recall.h:178)
+    d_ids = torch.empty((args.nq, args.k), dtype=torch.int32, device=dev)
+    d_dists = torch.empty((args.nq, args.k), dtype=torch.float32, device=dev)
+    d_vis = torch.empty(args.nq, dtype=torch.int32, device=dev)
+    d_cmps = torch.empty(args.nq, dtype=torch.int32, device=dev)
+    d_deg = torch.empty(args.nq, dtype=torch.int32, device=dev)
+    qp = QueryParams(k=args.k, beam=args.beam, cut=1.35, limit=args.n, degree_limit=args.R, rerank_factor=100, pad=1.0)
+    out = SearchOut(ids=d_ids.data_ptr(), dists=d_dists.data_ptr(), out_k=args.k, frontier_size=None,
+                    visited_count=d_vis.data_ptr(), dist_cmps=d_cmps.data_ptr(), degree_sum=d_deg.data_ptr(),
+                    visited_ids=None, visited_dists=None, visited_cap=0)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        check(lib.pann_batch_search_dev(ix.handle, d_q.data_ptr(), None, args.nq, args.d * 2, d_starts.data_ptr(), 1,
+                                        C.byref(qp), C.byref(out), C.c_void_p(stream.cuda_stream)))
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+
+    # ---- timed region: exactly --steps steps; per-launch HIP events on the launch stream ----
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier(); torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record(stream); step(); b.record(stream)
+    torch.cuda.synchronize(dev); barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    ms_per_step = elapsed * 1e3 / args.steps
+    qps = args.nq * world / (ms_per_step / 1e3)
+
+    # ---- algorithmic bytes per launch from the reference's own counters ----
+    vis = d_vis.cpu().numpy().astype(np.int64); cmps = d_cmps.cpu().numpy().astype(np.int64)
+    deg = d_deg.cpu().numpy().astype(np.int64)
+    esize = 2
+    bytes_q = cmps * args.d * esize + (vis + deg) * 4 + args.d * esize + args.k * 8
+    alg_bytes = int(bytes_q.sum())
+    achieved = alg_bytes / (kern_ms / 1e3) / 1e9
+
+    if rank == 0:
+        # recall against exact ground truth (device brute force; tie-aware like checkRecall)
+        gt_ids, gt_d = ix.bruteforce_knn(Q, 100)
+        rec = recall_at_k(d_ids.cpu().numpy().view(np.uint32), gt_ids, gt_d, args.k)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("n") == args.n and tj.get("nq") == args.nq and tj.get("beam") == args.beam:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "QPS @ recall@10>=0.95, SIFT-1M d=128 beam=64; achieved HBM GB/s vs roofline",
+            "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"SIFT-1M-shaped batched beam search: {args.n}x{args.d} integer-valued fp32->fp16 base, "
+                                   f"{args.nq} queries/step/GPU, beam={args.beam} k={args.k} cut=1.35 start=0, prebuilt "
+                                   f"Vamana R={args.R} L={args.L} alpha={args.alpha} x{args.passes} passes (built on device)",
+                       "n": args.n, "d": args.d, "nq_per_gpu": args.nq, "beam": args.beam, "k": args.k,
+                       "parallelism": f"query-sharded x{world}, index replicated, no collective"},
+            "recall_at_10": rec,
+            "avg_visited": float(vis.mean()), "avg_dist_cmps": float(cmps.mean()),
+            "build_s": build_s,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "beam_search_kernel", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(ix, Xf, Q.astype(np.float32), args)
+        print(json.dumps(res), flush=True)
+    ix.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(ix, Xf, Qf, args):
+    """The reference's CPU path for the same workload: the oracle (a port of filtered_beam_search,
+    one task per query like qsearchAll's parallel_for, beamSearch.h:556) on the host cores, float32
+    points as Euclidian_Point<float> would hold them, same graph (downloaded from the device).
+    Protocol of checkRecall: time only the batched search, several repetitions, best taken."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_api
+    o = oracle_api.load()
+    G = ix.get_graph()
+    threads = o.threads
+    best = None
+    reps = 0
+    t_all = time.time()
+    while reps < 5 and time.time() - t_all < 25.0:
+        t0 = time.perf_counter()
+        o.batch_search(Xf, G, queries=Qf, k=args.k, beam=args.beam, cut=1.35, threads=threads)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        reps += 1
+    return {"value": len(Qf) / best, "unit": "queries/s", "cores": threads, "kind": "port",
+            "sample": f"all {len(Qf)} queries of the step, {reps} repetitions, best; float32 base (reference type), "
+                      f"same device-built graph, {threads} std::threads"}
+
+
+if __name__ == "__main__":
+    main()

@@ -456,4 +456,118 @@ int pann_vamana_build(pann_index* idx, uint32_t R, uint32_t L, double alpha, int
   return PANN_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// distances, HCNNG leaf kNN, brute-force ground truth
+// ---------------------------------------------------------------------------------------------
+
+int pann_pair_distances(pann_index* idx, const uint32_t* a_ids, const uint32_t* b_ids, uint64_t m, float* out) {
+  if (int rc = check_idx(idx, "pann_pair_distances")) return rc;
+  if (m == 0) return PANN_OK;
+  if (!a_ids || !b_ids || !out) { set_error("pann_pair_distances: null argument"); return PANN_ERR_BAD_ARG; }
+  for (uint64_t i = 0; i < m; i++)
+    if (a_ids[i] >= idx->ix.n || b_ids[i] >= idx->ix.n) { set_error("pann_pair_distances: id out of range"); return PANN_ERR_BAD_ARG; }
+  DeviceGuard g(idx->device);
+  hipStream_t st = idx->stream;
+  if (int rc = idx->stage[2].ensure(m * 4)) return rc;
+  if (int rc = idx->stage[3].ensure(m * 4)) return rc;
+  if (int rc = idx->stage[4].ensure(m * 4)) return rc;
+  PANN_HIP(hipMemcpyAsync(idx->stage[2].p, a_ids, m * 4, hipMemcpyHostToDevice, st));
+  PANN_HIP(hipMemcpyAsync(idx->stage[3].p, b_ids, m * 4, hipMemcpyHostToDevice, st));
+  if (int rc = query_distances_dev(idx->ix, st, nullptr, 0, idx->stage[2].as<uint32_t>(), m, idx->stage[3].as<uint32_t>(), m, 1,
+                                   idx->stage[4].as<float>())) return rc;
+  PANN_HIP(hipMemcpyAsync(out, idx->stage[4].p, m * 4, hipMemcpyDeviceToHost, st));
+  PANN_HIP(hipStreamSynchronize(st));
+  return PANN_OK;
+}
+
+int pann_query_distances(pann_index* idx, const void* queries, uint64_t nq, uint64_t q_stride_bytes,
+                         const uint32_t* ids, uint64_t m, float* out) {
+  if (int rc = check_idx(idx, "pann_query_distances")) return rc;
+  if (nq == 0 || m == 0) return PANN_OK;
+  if (!queries || !ids || !out) { set_error("pann_query_distances: null argument"); return PANN_ERR_BAD_ARG; }
+  if (q_stride_bytes < idx->ix.dbytes) { set_error("pann_query_distances: query stride smaller than a row"); return PANN_ERR_BAD_ARG; }
+  for (uint64_t i = 0; i < m; i++)
+    if (ids[i] >= idx->ix.n) { set_error("pann_query_distances: id out of range"); return PANN_ERR_BAD_ARG; }
+  DeviceGuard g(idx->device);
+  hipStream_t st = idx->stream;
+  if (int rc = idx->stage[2].ensure(nq * q_stride_bytes + 16)) return rc;
+  if (int rc = idx->stage[3].ensure(m * 4)) return rc;
+  if (int rc = idx->stage[4].ensure(nq * m * 4)) return rc;
+  PANN_HIP(hipMemcpyAsync(idx->stage[2].p, queries, (nq - 1) * q_stride_bytes + idx->ix.dbytes, hipMemcpyHostToDevice, st));
+  PANN_HIP(hipMemcpyAsync(idx->stage[3].p, ids, m * 4, hipMemcpyHostToDevice, st));
+  if (int rc = query_distances_dev(idx->ix, st, idx->stage[2].as<uint8_t>(), q_stride_bytes, nullptr, nq,
+                                   idx->stage[3].as<uint32_t>(), m, 0, idx->stage[4].as<float>())) return rc;
+  PANN_HIP(hipMemcpyAsync(out, idx->stage[4].p, nq * m * 4, hipMemcpyDeviceToHost, st));
+  PANN_HIP(hipStreamSynchronize(st));
+  return PANN_OK;
+}
+
+int pann_leaf_knn_batch(pann_index* idx, const uint32_t* ids, const uint64_t* leaf_offsets, uint64_t nleaves,
+                        uint32_t m, uint32_t* out_ids, float* out_dists) {
+  if (int rc = check_idx(idx, "pann_leaf_knn_batch")) return rc;
+  if (nleaves == 0) return PANN_OK;
+  if (!ids || !leaf_offsets || !out_ids || !out_dists) { set_error("pann_leaf_knn: null argument"); return PANN_ERR_BAD_ARG; }
+  const uint64_t total = leaf_offsets[nleaves];
+  if (total == 0) return PANN_OK;
+  for (uint64_t i = 0; i < total; i++)
+    if (ids[i] >= idx->ix.n) { set_error("pann_leaf_knn: id out of range"); return PANN_ERR_BAD_ARG; }
+  std::vector<uint32_t> tseg, ta0;
+  for (uint64_t s = 0; s < nleaves; s++) {
+    if (leaf_offsets[s + 1] < leaf_offsets[s]) { set_error("pann_leaf_knn: offsets not monotone"); return PANN_ERR_BAD_ARG; }
+    for (uint64_t a = leaf_offsets[s]; a < leaf_offsets[s + 1]; a += 64) { tseg.push_back((uint32_t)s); ta0.push_back((uint32_t)a); }
+  }
+  DeviceGuard g(idx->device);
+  hipStream_t st = idx->stream;
+  const size_t nt = tseg.size();
+  if (int rc = idx->stage[2].ensure(total * 4)) return rc;
+  if (int rc = idx->stage[3].ensure((nleaves + 1) * 8)) return rc;
+  if (int rc = idx->stage[4].ensure(nt * 4)) return rc;
+  if (int rc = idx->stage[5].ensure(nt * 4)) return rc;
+  if (int rc = idx->stage[6].ensure(total * m * 4)) return rc;
+  if (int rc = idx->stage[7].ensure(total * m * 4)) return rc;
+  PANN_HIP(hipMemcpyAsync(idx->stage[2].p, ids, total * 4, hipMemcpyHostToDevice, st));
+  PANN_HIP(hipMemcpyAsync(idx->stage[3].p, leaf_offsets, (nleaves + 1) * 8, hipMemcpyHostToDevice, st));
+  PANN_HIP(hipMemcpyAsync(idx->stage[4].p, tseg.data(), nt * 4, hipMemcpyHostToDevice, st));
+  PANN_HIP(hipMemcpyAsync(idx->stage[5].p, ta0.data(), nt * 4, hipMemcpyHostToDevice, st));
+  if (int rc = dense_topk_dev(idx->ix, idx->ws2, st, nullptr, 0, idx->stage[2].as<uint32_t>(), idx->stage[2].as<uint32_t>(),
+                              idx->stage[3].as<uint64_t>(), idx->stage[3].as<uint64_t>(), idx->stage[4].as<uint32_t>(),
+                              idx->stage[5].as<uint32_t>(), (uint32_t)nt, total, total, 1, m, 1,
+                              idx->stage[6].as<uint32_t>(), idx->stage[7].as<float>())) return rc;
+  PANN_HIP(hipMemcpyAsync(out_ids, idx->stage[6].p, total * m * 4, hipMemcpyDeviceToHost, st));
+  PANN_HIP(hipMemcpyAsync(out_dists, idx->stage[7].p, total * m * 4, hipMemcpyDeviceToHost, st));
+  PANN_HIP(hipStreamSynchronize(st));
+  return PANN_OK;
+}
+
+int pann_leaf_knn(pann_index* idx, const uint32_t* ids, uint32_t N, uint32_t m, uint32_t* out_ids, float* out_dists) {
+  const uint64_t off[2] = {0, N};
+  return pann_leaf_knn_batch(idx, ids, off, 1, m, out_ids, out_dists);
+}
+
+int pann_bruteforce_knn(pann_index* idx, const void* queries, uint64_t nq, uint64_t q_stride_bytes, uint32_t k,
+                        uint32_t* out_ids, float* out_dists) {
+  if (int rc = check_idx(idx, "pann_bruteforce_knn")) return rc;
+  if (nq == 0) return PANN_OK;
+  if (!queries || !out_ids || !out_dists) { set_error("pann_bruteforce_knn: null argument"); return PANN_ERR_BAD_ARG; }
+  if (q_stride_bytes < idx->ix.dbytes) { set_error("pann_bruteforce_knn: query stride smaller than a row"); return PANN_ERR_BAD_ARG; }
+  DeviceGuard g(idx->device);
+  hipStream_t st = idx->stream;
+  if (int rc = idx->stage[2].ensure(nq * q_stride_bytes + 16)) return rc;
+  if (int rc = idx->stage[6].ensure(nq * k * 4)) return rc;
+  if (int rc = idx->stage[7].ensure(nq * k * 4)) return rc;
+  PANN_HIP(hipMemcpyAsync(idx->stage[2].p, queries, (nq - 1) * q_stride_bytes + idx->ix.dbytes, hipMemcpyHostToDevice, st));
+  const uint32_t ntiles = (uint32_t)((nq + 63) / 64);
+  // enough workgroups to fill 256 CUs a few times over, B pieces of at least 4096 rows
+  uint32_t nsplit = std::max<uint32_t>(1, std::min<uint32_t>((2048 + ntiles - 1) / ntiles, (uint32_t)((idx->ix.n + 4095) / 4096)));
+  nsplit = std::min<uint32_t>(nsplit, 64);
+  if (int rc = dense_topk_dev(idx->ix, idx->ws2, st, idx->stage[2].as<uint8_t>(), q_stride_bytes, nullptr, nullptr, nullptr,
+                              nullptr, nullptr, nullptr, ntiles, nq, idx->ix.n, nsplit, k, 0, idx->stage[6].as<uint32_t>(),
+                              idx->stage[7].as<float>())) return rc;
+  PANN_HIP(hipMemcpyAsync(out_ids, idx->stage[6].p, nq * k * 4, hipMemcpyDeviceToHost, st));
+  PANN_HIP(hipMemcpyAsync(out_dists, idx->stage[7].p, nq * k * 4, hipMemcpyDeviceToHost, st));
+  PANN_HIP(hipStreamSynchronize(st));
+  return PANN_OK;
+}
+
 }  // extern "C"

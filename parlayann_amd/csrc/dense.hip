@@ -1,0 +1,305 @@
+// dense.hip -- dense all-pairs distances with a per-row top-m, on gfx950.
+//
+//   hcnng_index::MSTk  HCNNG/hcnng_index.h:145-181  all N*(N-1) leaf distances, 10 smallest per row
+//   compute_groundtruth  data_tools/compute_groundtruth.cpp:22-59  exact kNN of every query
+//
+// Tiling: a 256-thread workgroup owns 64 A-rows (16 per wave) and streams B in tiles of 64 rows;
+// both tiles are staged in LDS in 256-byte dimension segments (B padded by 16 B per row so the
+// lane-per-row ds_read_b128 is conflict free, A read as broadcasts).  Lane l of a wave holds the
+// running distances of B-row l to the wave's 16 A-rows in registers, so a B tile is read from HBM
+// once per 64 A-rows.  The per-row top-m lists live in LDS and are touched only when a distance
+// beats the row's current m-th best (rare after the first tiles).
+//
+// Arithmetic is the same dist_accum as the gather kernels (exact for integer types; for float
+// types one lane sums a whole row left to right in 16-byte chunks).
+#include <vector>
+
+#include "pann_device.h"
+
+namespace pann {
+
+constexpr int DT_A = 64;        // A rows per workgroup
+constexpr int DT_AW = 16;       // A rows per wave
+constexpr int DT_B = 64;        // B rows per tile (one per lane)
+constexpr int DT_SEG = 256;     // bytes of the dimension staged per step
+constexpr int DT_BSTRIDE = DT_SEG + 16;
+
+struct DenseArgs {
+  const uint8_t* points; uint32_t pstride; uint32_t dbytes;
+  // A rows: external vectors (a_ext, stride) or point ids (a_ids) -- per segment ranges below
+  const uint8_t* a_ext; uint64_t a_stride; const uint32_t* a_ids;
+  // B rows: point ids (b_ids) or the contiguous range of all points
+  const uint32_t* b_ids;
+  // segments (leaves): A rows [a_off[s], a_off[s+1]) against B rows [b_off[s], b_off[s+1]);
+  const uint64_t* a_off; const uint64_t* b_off;   // device arrays, nseg+1 (null: one segment 0..na / 0..nb)
+  uint64_t na, nb;
+  uint32_t nsplit;            // B range of a segment is cut into nsplit pieces (grid.y)
+  uint32_t m, mcap;           // top-m; mcap = m rounded up to 64
+  int exclude_same_id;        // leaf mode: skip j == i (hcnng_index.h:153)
+  uint64_t* partial;          // [total A rows][nsplit][m] keys
+  const uint32_t* tile_seg;   // [grid.x] segment of each A tile
+  const uint32_t* tile_a0;    // [grid.x] first A row (global index) of each tile
+};
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// sorted insert of key x into list[0..mcap) (ascending, KEY_INF padded), dropping the last entry
+__device__ __forceinline__ void list_insert(uint64_t* list, uint32_t mcap, uint64_t x, int lane) {
+  uint64_t nv[2];
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const uint32_t i = lane + r * 64;
+    nv[r] = KEY_INF;
+    if (i < mcap) {
+      const uint64_t cur = list[i];
+      const bool prev_lt = (i == 0) ? true : (list[i - 1] < x);
+      nv[r] = (cur < x) ? cur : (prev_lt ? x : list[i - 1]);
+    }
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const uint32_t i = lane + r * 64;
+    if (i < mcap) list[i] = nv[r];
+  }
+  wave_lds_sync();
+}
+
+template <int DT, int METRIC>
+__global__ void __launch_bounds__(256) dense_topk_kernel(DenseArgs A) {
+  using acc_t = typename AccT<DT>::type;
+  extern __shared__ __align__(16) uint8_t smem[];
+  uint8_t* At = smem;                                   // [64][DT_SEG]
+  uint8_t* Bt = At + DT_A * DT_SEG;                     // [64][DT_BSTRIDE]
+  uint32_t* Bid = reinterpret_cast<uint32_t*>(Bt + DT_B * DT_BSTRIDE);   // [64] ids of the B tile
+  uint32_t* Aid = Bid + DT_B;                           // [64] ids of the A tile (SENTINEL: none)
+  uint64_t* lists = reinterpret_cast<uint64_t*>(Aid + DT_A);            // [64][mcap]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t seg = A.tile_seg ? A.tile_seg[blockIdx.x] : 0u;
+  const uint64_t a_lo = A.a_off ? A.a_off[seg] : 0ull, a_hi = A.a_off ? A.a_off[seg + 1] : A.na;
+  const uint64_t b_lo = A.b_off ? A.b_off[seg] : 0ull, b_hi = A.b_off ? A.b_off[seg + 1] : A.nb;
+  const uint64_t a0 = A.tile_a0 ? (uint64_t)A.tile_a0[blockIdx.x] : (uint64_t)blockIdx.x * DT_A;
+  const uint32_t na_tile = (uint32_t)min((uint64_t)DT_A, a_hi - a0);
+  (void)a_lo;
+  // this block's share of the B range
+  const uint64_t nb_seg = b_hi - b_lo;
+  const uint64_t per = ((nb_seg + A.nsplit - 1) / A.nsplit + DT_B - 1) / DT_B * DT_B;
+  const uint64_t bs = b_lo + min(nb_seg, (uint64_t)blockIdx.y * per);
+  const uint64_t be = b_lo + min(nb_seg, (uint64_t)(blockIdx.y + 1) * per);
+
+  for (uint32_t i = tid; i < DT_A * A.mcap; i += 256) lists[i] = KEY_INF;
+  if (tid < DT_A) Aid[tid] = (tid < (int)na_tile && A.a_ids) ? A.a_ids[a0 + tid] : SENTINEL;
+  __syncthreads();
+
+  const uint32_t nseg = (A.pstride + DT_SEG - 1) / DT_SEG;
+  // stage one 256-byte segment of 64 rows: 16 lanes x 16 B per row, 16 rows per pass of 256 threads
+  auto stage_rows = [&](uint8_t* dst, uint32_t dstride, uint32_t sg, auto rowptr, auto rowvalid, uint32_t nrows) {
+    const int r0 = tid >> 4, c = tid & 15;
+    for (int r = r0; r < 64; r += 16) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      const uint32_t off = sg * DT_SEG + c * 16;
+      if (r < (int)nrows) {
+        const uint8_t* rp = rowptr(r);
+        const uint32_t valid = rowvalid();
+        if ((reinterpret_cast<uintptr_t>(rp) & 15) == 0) v = load16_guarded(rp, off, valid);
+        else {
+          uint8_t tmp[16];
+#pragma unroll
+          for (int i = 0; i < 16; i++) tmp[i] = (off + i < valid) ? rp[off + i] : (uint8_t)0;
+          __builtin_memcpy(&v, tmp, 16);
+        }
+      }
+      *reinterpret_cast<uint4*>(dst + (size_t)r * dstride + c * 16) = v;
+    }
+  };
+  auto a_rowptr = [&](int r) -> const uint8_t* {
+    return A.a_ids ? A.points + (uint64_t)A.a_ids[a0 + r] * A.pstride : A.a_ext + (a0 + r) * A.a_stride;
+  };
+  auto a_valid = [&]() -> uint32_t { return A.a_ids ? A.pstride : A.dbytes; };
+
+  if (nseg == 1) { stage_rows(At, DT_SEG, 0, a_rowptr, a_valid, na_tile); }
+
+  for (uint64_t bt = bs; bt < be; bt += DT_B) {
+    const uint32_t nb_tile = (uint32_t)min((uint64_t)DT_B, be - bt);
+    auto b_rowptr = [&](int r) -> const uint8_t* {
+      const uint64_t id = A.b_ids ? (uint64_t)A.b_ids[bt + r] : (bt + r);
+      return A.points + id * A.pstride;
+    };
+    auto b_valid = [&]() -> uint32_t { return A.pstride; };
+    acc_t acc[DT_AW];
+#pragma unroll
+    for (int a = 0; a < DT_AW; a++) acc[a] = 0;
+    __syncthreads();          // previous tile's readers are done with Bt / Bid
+    if (tid < DT_B) Bid[tid] = tid < (int)nb_tile ? (A.b_ids ? A.b_ids[bt + tid] : (uint32_t)(bt + tid)) : SENTINEL;
+    for (uint32_t sg = 0; sg < nseg; sg++) {
+      if (sg > 0) __syncthreads();
+      stage_rows(Bt, DT_BSTRIDE, sg, b_rowptr, b_valid, nb_tile);
+      if (nseg > 1) stage_rows(At, DT_SEG, sg, a_rowptr, a_valid, na_tile);
+      __syncthreads();
+      const uint32_t nchunk = min((uint32_t)DT_SEG, A.pstride - sg * DT_SEG) / 16;
+      for (uint32_t c = 0; c < nchunk; c++) {
+        const uint4 b = *reinterpret_cast<const uint4*>(Bt + (size_t)lane * DT_BSTRIDE + c * 16);
+#pragma unroll
+        for (int a = 0; a < DT_AW; a++) {
+          const uint4 q = *reinterpret_cast<const uint4*>(At + (size_t)(wave * DT_AW + a) * DT_SEG + c * 16);
+          dist_accum<DT, METRIC>(acc[a], b, q);
+        }
+      }
+    }
+    // ---- top-m update: wave-private lists of its 16 A rows ----
+    const uint32_t bid = Bid[lane];
+#pragma unroll
+    for (int a = 0; a < DT_AW; a++) {
+      const uint32_t ar = wave * DT_AW + a;
+      if (ar >= na_tile) break;               // uniform per wave
+      uint64_t* list = lists + (size_t)ar * A.mcap;
+      const float dist = dist_finish<DT, METRIC>(acc[a]);
+      const uint64_t key = make_key(dist, bid);
+      bool ok = (lane < (int)nb_tile);
+      if (A.exclude_same_id) ok = ok && (bid != Aid[ar]);
+      uint64_t tau = list[A.m - 1];
+      uint64_t mask = __ballot(ok && key < tau);
+      while (mask) {
+        const int L = __ffsll((unsigned long long)mask) - 1;
+        const uint32_t klo = __builtin_amdgcn_readlane((uint32_t)key, L);
+        const uint32_t khi = __builtin_amdgcn_readlane((uint32_t)(key >> 32), L);
+        const uint64_t x = ((uint64_t)khi << 32) | klo;
+        mask &= mask - 1;
+        if (x < tau) {
+          list_insert(list, A.mcap, x, lane);
+          tau = list[A.m - 1];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- emit this block's partial lists ----
+  for (uint32_t i = tid; i < na_tile * A.m; i += 256) {
+    const uint32_t ar = i / A.m, j = i % A.m;
+    A.partial[((a0 + ar) * A.nsplit + blockIdx.y) * A.m + j] = lists[(size_t)ar * A.mcap + j];
+  }
+}
+
+// merge the nsplit partial lists of each A row (one wave per row) and write ids / dists
+__global__ void __launch_bounds__(64) dense_merge_kernel(const uint64_t* partial, uint64_t na, uint32_t nsplit,
+                                                         uint32_t m, uint32_t mcap, uint32_t* out_ids, float* out_dists) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  uint64_t* list = reinterpret_cast<uint64_t*>(smem);
+  const int lane = threadIdx.x;
+  const uint64_t ar = blockIdx.x;
+  for (uint32_t i = lane; i < mcap; i += 64) list[i] = KEY_INF;
+  wave_lds_sync();
+  const uint64_t* src = partial + ar * nsplit * m;
+  const uint32_t total = nsplit * m;
+  for (uint32_t i0 = 0; i0 < total; i0 += 64) {
+    const uint32_t i = i0 + lane;
+    const uint64_t key = i < total ? src[i] : KEY_INF;
+    uint64_t tau = list[m - 1];
+    uint64_t mask = __ballot(key < tau);
+    while (mask) {
+      const int L = __ffsll((unsigned long long)mask) - 1;
+      const uint32_t klo = __builtin_amdgcn_readlane((uint32_t)key, L);
+      const uint32_t khi = __builtin_amdgcn_readlane((uint32_t)(key >> 32), L);
+      const uint64_t x = ((uint64_t)khi << 32) | klo;
+      mask &= mask - 1;
+      if (x < tau) { list_insert(list, mcap, x, lane); tau = list[m - 1]; }
+    }
+  }
+  for (uint32_t j = lane; j < m; j += 64) {
+    const uint64_t k = list[j];
+    out_ids[ar * m + j] = (k == KEY_INF) ? SENTINEL : key_id(k);
+    out_dists[ar * m + j] = (k == KEY_INF) ? __builtin_inff() : key_dist(k);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+
+static size_t dense_lds_bytes(uint32_t mcap) {
+  return (size_t)DT_A * DT_SEG + (size_t)DT_B * DT_BSTRIDE + (DT_A + DT_B) * 4 + (size_t)DT_A * mcap * 8;
+}
+
+// Runs the dense top-m.  All pointers device.  tile arrays may be null for a single segment.
+int dense_topk_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, const uint8_t* d_a_ext, uint64_t a_stride,
+                   const uint32_t* d_a_ids, const uint32_t* d_b_ids, const uint64_t* d_a_off, const uint64_t* d_b_off,
+                   const uint32_t* d_tile_seg, const uint32_t* d_tile_a0, uint32_t ntiles, uint64_t na, uint64_t nb,
+                   uint32_t nsplit, uint32_t m, int exclude_same, uint32_t* d_out_ids, float* d_out_dists) {
+  if (m == 0 || m > 128) { set_error("dense top-m: m must be in [1,128]"); return PANN_ERR_BAD_ARG; }
+  if (na == 0) return PANN_OK;
+  const uint32_t mcap = (m + 63) / 64 * 64;
+  const size_t pbytes = (size_t)na * nsplit * m * 8;
+  if (int rc = ws.ensure(pbytes + 256)) return rc;
+  DenseArgs A{};
+  A.points = ix.points; A.pstride = ix.pstride; A.dbytes = ix.dbytes;
+  A.a_ext = d_a_ext; A.a_stride = a_stride; A.a_ids = d_a_ids; A.b_ids = d_b_ids;
+  A.a_off = d_a_off; A.b_off = d_b_off; A.na = na; A.nb = nb; A.nsplit = nsplit; A.m = m; A.mcap = mcap;
+  A.exclude_same_id = exclude_same; A.partial = (uint64_t*)ws.buf; A.tile_seg = d_tile_seg; A.tile_a0 = d_tile_a0;
+  const size_t lds = dense_lds_bytes(mcap);
+  const dim3 grid(ntiles, nsplit);
+#define CALL_DENSE(DT, MT)                                                                              \
+  do {                                                                                                   \
+    auto kern = dense_topk_kernel<DT, MT>;                                                               \
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, A);                                               \
+  } while (0)
+  if (ix.dtype == PANN_U8 && ix.metric == PANN_L2) CALL_DENSE(PANN_U8, PANN_L2);
+  else if (ix.dtype == PANN_U8) CALL_DENSE(PANN_U8, PANN_MIPS);
+  else if (ix.dtype == PANN_I8 && ix.metric == PANN_L2) CALL_DENSE(PANN_I8, PANN_L2);
+  else if (ix.dtype == PANN_I8) CALL_DENSE(PANN_I8, PANN_MIPS);
+  else if (ix.dtype == PANN_F32 && ix.metric == PANN_L2) CALL_DENSE(PANN_F32, PANN_L2);
+  else if (ix.dtype == PANN_F32) CALL_DENSE(PANN_F32, PANN_MIPS);
+  else if (ix.dtype == PANN_F16 && ix.metric == PANN_L2) CALL_DENSE(PANN_F16, PANN_L2);
+  else CALL_DENSE(PANN_F16, PANN_MIPS);
+#undef CALL_DENSE
+  PANN_HIP(hipGetLastError());
+  hipLaunchKernelGGL(dense_merge_kernel, dim3((uint32_t)na), dim3(64), (size_t)mcap * 8, st,
+                     (const uint64_t*)ws.buf, na, nsplit, m, mcap, d_out_ids, d_out_dists);
+  PANN_HIP(hipGetLastError());
+  return PANN_OK;
+}
+
+// pair / query-vs-ids distances (Point::distance): one group of LPC lanes per pair
+template <int DT, int METRIC, int LPC, bool NCH1>
+__global__ void __launch_bounds__(PANN_WAVE) query_distances_kernel(PointsView pv, uint32_t dbytes, const uint8_t* q_ext,
+                                                                    uint64_t q_stride, const uint32_t* q_ids,
+                                                                    const uint32_t* ids, uint64_t m, int paired,
+                                                                    float* out) {
+  // paired: out[i] = d(q_ids[i], ids[i]) -- one wave per 64 pairs is wasteful; one wave per QUERY otherwise
+  const int lane = threadIdx.x;
+  __shared__ uint32_t Pl[PANN_WAVE];
+  extern __shared__ __align__(16) uint8_t smem[];
+  uint4* qlds = reinterpret_cast<uint4*>(smem);
+  const uint64_t qi = blockIdx.x;
+  const uint8_t* qrow = q_ids ? pv.points + (uint64_t)q_ids[qi] * pv.pstride : q_ext + qi * q_stride;
+  uint4 qreg = make_uint4(0, 0, 0, 0);
+  load_query<LPC, NCH1>(qrow, q_ids ? pv.pstride : dbytes, pv.nch, qreg, qlds, lane);
+  __syncthreads();
+  const uint64_t j_lo = paired ? qi : 0, j_hi = paired ? qi + 1 : m;
+  for (uint64_t j0 = j_lo; j0 < j_hi; j0 += PANN_WAVE) {
+    const uint32_t mm = (uint32_t)min((uint64_t)PANN_WAVE, j_hi - j0);
+    if (lane < (int)mm) Pl[lane] = ids[j0 + lane];
+    __syncthreads();
+    gather_tile<DT, METRIC, LPC, NCH1, 4>(pv, qreg, qlds, Pl, mm, lane,
+      [&](bool has, uint32_t ci, uint32_t, float dist) {
+        if (has) out[paired ? qi : qi * m + j0 + ci] = dist;
+      });
+    __syncthreads();
+  }
+}
+
+int query_distances_dev(const DeviceIndex& ix, hipStream_t st, const uint8_t* d_q_ext, uint64_t q_stride,
+                        const uint32_t* d_q_ids, uint64_t nq, const uint32_t* d_ids, uint64_t m, int paired,
+                        float* d_out) {
+  if (nq == 0) return PANN_OK;
+  const PointsView pv{ix.points, ix.pstride, ix.nch};
+  const size_t qb = ix.nch == 1 ? 0 : (size_t)ix.nch * ix.lpc * 16;
+#define CALL_QD(DT, MT, L, N1) hipLaunchKernelGGL((query_distances_kernel<DT, MT, L, N1>), dim3((uint32_t)nq), dim3(PANN_WAVE), qb, st, pv, ix.dbytes, d_q_ext, q_stride, d_q_ids, d_ids, m, paired, d_out)
+  PANN_TYPE_SWITCH(ix, CALL_QD);
+#undef CALL_QD
+  PANN_HIP(hipGetLastError());
+  return PANN_OK;
+}
+
+}  // namespace pann

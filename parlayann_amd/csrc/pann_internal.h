@@ -67,4 +67,13 @@ int insert_batch_dev(const DeviceIndex& ix, Workspace& ws, Workspace& ws2, Works
                      uint32_t* vcap_io, pann_build_stats* stats);
 int sort_neighbors_dev(const DeviceIndex& ix, hipStream_t st);
 
+// dense.hip
+int dense_topk_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, const uint8_t* d_a_ext, uint64_t a_stride,
+                   const uint32_t* d_a_ids, const uint32_t* d_b_ids, const uint64_t* d_a_off, const uint64_t* d_b_off,
+                   const uint32_t* d_tile_seg, const uint32_t* d_tile_a0, uint32_t ntiles, uint64_t na, uint64_t nb,
+                   uint32_t nsplit, uint32_t m, int exclude_same, uint32_t* d_out_ids, float* d_out_dists);
+int query_distances_dev(const DeviceIndex& ix, hipStream_t st, const uint8_t* d_q_ext, uint64_t q_stride,
+                        const uint32_t* d_q_ids, uint64_t nq, const uint32_t* d_ids, uint64_t m, int paired,
+                        float* d_out);
+
 }  // namespace pann

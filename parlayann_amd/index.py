@@ -150,3 +150,34 @@ class DeviceIndex:
         check(self._lib.pann_vamana_build(self._h, R, L, float(alpha), num_passes, seed, 1 if sort_neighbors else 0,
                                           C.byref(st)))
         return st
+
+    # ---- distances / dense all-pairs ----
+    def pair_distances(self, a_ids, b_ids):
+        a = np.ascontiguousarray(a_ids, dtype=np.uint32); b = np.ascontiguousarray(b_ids, dtype=np.uint32)
+        out = np.empty(len(a), np.float32)
+        check(self._lib.pann_pair_distances(self._h, _ptr(a), _ptr(b), len(a), _ptr(out)))
+        return out
+
+    def query_distances(self, queries, ids):
+        q = np.ascontiguousarray(queries); ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        out = np.empty((len(q), len(ids)), np.float32)
+        check(self._lib.pann_query_distances(self._h, _ptr(q), len(q), q.strides[0], _ptr(ids), len(ids), _ptr(out)))
+        return out
+
+    def leaf_knn_batch(self, ids, leaf_offsets, m):
+        """hcnng_index.h:145-181 for many leaves: per member the m nearest other members."""
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        off = np.ascontiguousarray(leaf_offsets, dtype=np.uint64)
+        oi = np.empty((len(ids), m), np.uint32); od = np.empty((len(ids), m), np.float32)
+        check(self._lib.pann_leaf_knn_batch(self._h, _ptr(ids), _ptr(off), len(off) - 1, m, _ptr(oi), _ptr(od)))
+        return oi, od
+
+    def leaf_knn(self, ids, m):
+        return self.leaf_knn_batch(ids, [0, len(ids)], m)
+
+    def bruteforce_knn(self, queries, k):
+        """data_tools/compute_groundtruth.cpp:22-59."""
+        q = np.ascontiguousarray(queries)
+        oi = np.empty((len(q), k), np.uint32); od = np.empty((len(q), k), np.float32)
+        check(self._lib.pann_bruteforce_knn(self._h, _ptr(q), len(q), q.strides[0], k, _ptr(oi), _ptr(od)))
+        return oi, od
