@@ -163,6 +163,18 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cpus():
+    """host cores this process may really use: affinity mask capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(ix, Xf, Qf, args):
     """The reference's CPU path for the same workload: the oracle (a port of filtered_beam_search,
     one task per query like qsearchAll's parallel_for, beamSearch.h:556) on the host cores, float32
@@ -172,7 +184,7 @@ def cpu_baseline(ix, Xf, Qf, args):
     import oracle_api
     o = oracle_api.load()
     G = ix.get_graph()
-    threads = o.threads
+    threads = usable_cpus()
     best = None
     reps = 0
     t_all = time.time()
