@@ -106,7 +106,7 @@ __device__ __forceinline__ bool filter_update(uint32_t* H, uint32_t hmask, bool 
 // Distances from the query to the m ids in Pl[0..m); survivors of `dist < cutoff` (:157) are
 // appended to C in row order.
 template <int DT, int METRIC, int LPC, bool NCH1, int U>
-__device__ __forceinline__ uint32_t gather_distances(const BSParams& P, const uint4& qreg,
+__device__ __forceinline__ uint32_t gather_distances(const BSParams& P, const QReg<DT>& qreg,
                                                      const uint4* qlds, const uint32_t* Pl, uint32_t m,
                                                      uint32_t cutoff_ord, uint64_t* C, uint32_t c, int lane) {
   const PointsView PV{P.points, P.pstride, P.nch};
@@ -125,17 +125,17 @@ template <int DT, int METRIC, int LPC, bool NCH1, bool HASH_LDS>
 __global__ void __launch_bounds__(PANN_WAVE) beam_search_kernel(BSParams P) {
   const int lane = threadIdx.x;
   extern __shared__ __align__(16) uint8_t smem[];
-  // ---- LDS carve (all regions 16 B aligned) ----
+  // ---- LDS carve (all regions 16 B aligned): 6.4 KB at beam 64 / degree 64 -> 24 queries per CU ----
   uint64_t* F = reinterpret_cast<uint64_t*>(smem);       // [bcap] frontier keys
-  uint64_t* NF = F + P.bcap;                             // [bcap] merge output (swapped with F)
+  uint64_t* NF = F + P.bcap;                             // [bcap] merge output (swapped with F); between
+                                                         //        merges its first 256 B hold Pl
   uint64_t* C = NF + P.bcap;                             // [ccap] candidates (unsorted)
-  uint64_t* S = C + P.ccap;                              // [ccap] valid candidates, sorted
-  uint32_t* Fv = reinterpret_cast<uint32_t*>(S + P.ccap);  // [bcap] 0 unvisited, 1 visited, 2 visited+listed
-  uint32_t* NFv = Fv + P.bcap;                           // [bcap]
-  uint32_t* CP = NFv + P.bcap;                           // [ccap] candidate's lower_bound in F
-  uint32_t* Pl = CP + P.ccap;                            // [64] filter survivors of one row chunk
-  uint4* qlds = reinterpret_cast<uint4*>(Pl + 64);       // [nch*LPC] query (generic variant)
+  uint8_t* Fv = reinterpret_cast<uint8_t*>(C + P.ccap);  // [bcap] 0 unvisited, 1 visited, 2 visited+listed
+  uint8_t* NFv = Fv + P.bcap;                            // [bcap]
+  uint16_t* CP = reinterpret_cast<uint16_t*>(NFv + P.bcap);  // [ccap] candidate's lower_bound in F
+  uint4* qlds = reinterpret_cast<uint4*>(CP + P.ccap);   // [nch*LPC] query (generic variant)
   uint32_t* Hl = reinterpret_cast<uint32_t*>(qlds + (NCH1 ? 0 : P.nch * LPC));  // [1<<bits] if HASH_LDS
+#define PANN_PL (reinterpret_cast<uint32_t*>(NF))        /* [64] filter survivors of one row chunk */
 
   const uint32_t hsize = 1u << P.bits, hmask = hsize - 1u;
   const uint32_t beam = P.beam;
@@ -155,8 +155,8 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_kernel(BSParams P) {
     // ---- query vector -> registers (one chunk) or LDS (generic) ----
     const int64_t self = P.query_ids ? (int64_t)P.query_ids[qi] : -1;
     const uint8_t* qrow = P.query_ids ? P.points + (uint64_t)self * P.pstride : P.queries + (uint64_t)qi * P.qstride;
-    uint4 qreg = make_uint4(0, 0, 0, 0);
-    load_query<LPC, NCH1>(qrow, P.dbytes, P.nch, qreg, qlds, lane);
+    QReg<DT> qreg{};
+    load_query<DT, LPC, NCH1>(qrow, P.dbytes, P.nch, qreg, qlds, lane);
     hsync<HASH_LDS>();
 
     uint32_t f = 0;        // frontier size
@@ -174,11 +174,11 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_kernel(BSParams P) {
       const bool act = i < P.nstarts;
       const uint32_t a = act ? P.starts[i] : 0u;
       (void)filter_update<HASH_LDS>(H, hmask, act, a, lane);
-      if (act) Pl[lane] = a;
+      if (act) PANN_PL[lane] = a;
       __syncthreads();
       const uint32_t m = min(P.nstarts - s0, (uint32_t)PANN_WAVE);
       // every start enters the frontier: cutoff above any finite distance
-      c = gather_distances<DT, METRIC, LPC, NCH1, 4>(P, qreg, qlds, Pl, m, 0xFFFFFFFFu, C, c, lane);
+      c = gather_distances<DT, METRIC, LPC, NCH1, 4>(P, qreg, qlds, PANN_PL, m, 0xFFFFFFFFu, C, c, lane);
       __syncthreads();
     }
 
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_kernel(BSParams P) {
         uint32_t unv_total = 0;
         for (uint32_t e0 = 0; e0 < f; e0 += PANN_WAVE) {
           const uint32_t e = e0 + lane;
-          const uint64_t um = __ballot(e < f && Fv[e] == 0u);
+          const uint64_t um = __ballot(e < f && Fv[e] == 0);
           if (cur_idx < 0 && um) cur_idx = (int)e0 + __ffsll((unsigned long long)um) - 1;
           unv_total += __popcll(um);
         }
@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_kernel(BSParams P) {
         const uint32_t cur = key_id(cur_key);
         // ---- visited.insert(current) (:112-114) ----
         if (lane == 0) {
-          Fv[cur_idx] = 1u;
+          Fv[cur_idx] = 1;
           if (P.out.visited_cap) {
             if (nvis < P.out.visited_cap) {
               if (P.out.visited_ids) P.out.visited_ids[(size_t)qi * P.out.visited_cap + nvis] = cur;
@@ -229,10 +229,10 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_kernel(BSParams P) {
           const bool keep = act && !seen && ((int64_t)a != self);     // :133
           const uint64_t km = __ballot(keep);
           const uint32_t m = __popcll(km);
-          if (keep) Pl[lanes_below(km, lane)] = a;
+          if (keep) PANN_PL[lanes_below(km, lane)] = a;
           dcmps += m;                                                 // :137,155
           __syncthreads();
-          if (m) c = gather_distances<DT, METRIC, LPC, NCH1, 4>(P, qreg, qlds, Pl, m, cutoff_ord, C, c, lane);
+          if (m) c = gather_distances<DT, METRIC, LPC, NCH1, 4>(P, qreg, qlds, PANN_PL, m, cutoff_ord, C, c, lane);
           __syncthreads();
         }
         // ---- skip the merge while too few candidates (:162-168) ----
@@ -256,41 +256,37 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_kernel(BSParams P) {
             if (dead) key = KEY_INF;
           }
           __syncthreads();       // all reads of C[0..j) by this chunk are done
-          if (j < c) { C[j] = key; CP[j] = p; }
+          if (j < c) { C[j] = key; CP[j] = (uint16_t)p; }
           // later chunks compare against earlier ORIGINAL keys; a killed earlier key was itself a
           // duplicate of a still earlier live one (or of F), so the verdict is unchanged.
           __syncthreads();
         }
-        // A2: rank among live candidates -> sorted S, and direct placement into NF
+        // A2: rank among live candidates -> direct placement into NF
         uint32_t nvalid = 0;
         for (uint32_t j0 = 0; j0 < c; j0 += PANN_WAVE) {
           const uint32_t j = j0 + lane;
           const uint64_t key = j < c ? C[j] : KEY_INF;
           nvalid += __popcll(__ballot(key != KEY_INF));
-        }
-        for (uint32_t j0 = 0; j0 < c; j0 += PANN_WAVE) {
-          const uint32_t j = j0 + lane;
-          const uint64_t key = j < c ? C[j] : KEY_INF;
           if (key != KEY_INF) {
             uint32_t r = 0;
-            for (uint32_t i = 0; i < c; i++) r += (C[i] < key) ? 1u : 0u;
-            S[r] = key;
+            for (uint32_t i = 0; i < c; i++) r += (C[i] < key) ? 1u : 0u;   // dead entries are KEY_INF
             const uint32_t pos = r + CP[j];
             if (pos < beam) {
               uint32_t flag = 0u;   // re-entry of an already visited vertex? (only while not full)
               for (uint32_t t = 0; t < ndrop; t++)
                 flag |= (__hip_atomic_load(DL + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key) ? 2u : 0u;
-              NF[pos] = key; NFv[pos] = flag;
+              NF[pos] = key; NFv[pos] = (uint8_t)flag;
             }
           }
         }
-        __syncthreads();
         // B: old frontier entries move right by the number of live candidates below them
         for (uint32_t e0 = 0; e0 < f; e0 += PANN_WAVE) {
           const uint32_t e = e0 + lane;
           if (e < f) {
             const uint64_t key = F[e];
-            const uint32_t pos = e + lower_bound_lds(S, nvalid, key);
+            uint32_t below = 0;
+            for (uint32_t i = 0; i < c; i++) below += (C[i] < key) ? 1u : 0u;
+            const uint32_t pos = e + below;
             if (pos < beam) { NF[pos] = key; NFv[pos] = Fv[e]; }
           }
         }
@@ -318,10 +314,11 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_kernel(BSParams P) {
             const uint32_t e = e0 + lane;
             bool lost = false;
             uint64_t key = 0;
-            if (e < f_old && Fv[e] == 1u) {
+            if (e < f_old && Fv[e] == 1) {
               key = F[e];
-              const uint32_t pos = e + lower_bound_lds(S, nvalid, key);
-              lost = pos >= f_new;
+              uint32_t below = 0;
+              for (uint32_t i = 0; i < c; i++) below += (C[i] < key) ? 1u : 0u;
+              lost = (e + below) >= f_new;
             }
             const uint64_t lm = __ballot(lost);
             if (lost) {
@@ -334,7 +331,7 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_kernel(BSParams P) {
           __builtin_amdgcn_s_waitcnt(0);   // dropped-list stores visible to this wave's later loads
         }
         // visited entries with flag 2 that stay in the frontier keep flag 2 (== visited)
-        { uint64_t* t = F; F = NF; NF = t; uint32_t* tv = Fv; Fv = NFv; NFv = tv; }
+        { uint64_t* t = F; F = NF; NF = t; uint8_t* tv = Fv; Fv = NFv; NFv = tv; }
         f = f_new;
         c = 0;                      // candidates.clear() (:182)
         __syncthreads();
@@ -400,11 +397,11 @@ static Plan make_plan(const DeviceIndex& ix, const SearchArgs& a) {
   int64_t dl = std::min<int64_t>(std::max<int64_t>(a.degree_limit, 0), (int64_t)ix.max_deg);
   p.deg_eff = (uint32_t)dl;
   // at merge time |C| <= (beam/8 - 1) + deg_eff (accumulation stops at beam/8); starts first
-  p.ccap = (std::max<uint32_t>(beam / 8 + p.deg_eff, a.nstarts) + 63) / 64 * 64 + 64;
+  p.ccap = (std::max<uint32_t>(beam / 8 + p.deg_eff, a.nstarts) + 63) / 64 * 64;
   p.dcap = 256;
   const bool nch1 = (ix.nch == 1);
-  size_t fixed = (size_t)p.bcap * 8 * 2 + (size_t)p.ccap * 8 * 2 + (size_t)p.bcap * 4 * 2 +
-                 (size_t)p.ccap * 4 + 64 * 4 + (nch1 ? 0 : (size_t)ix.nch * ix.lpc * 16);
+  size_t fixed = (size_t)p.bcap * 8 * 2 + (size_t)p.ccap * 8 + (size_t)p.bcap * 2 +
+                 (size_t)p.ccap * 2 + (nch1 ? 0 : (size_t)ix.nch * ix.lpc * 16);
   size_t hbytes = (size_t)4 << p.bits;
   p.hash_lds = (hbytes <= 16384) && (fixed + hbytes <= 64 * 1024);
   p.lds_bytes = (uint32_t)(fixed + (p.hash_lds ? hbytes : 0));

@@ -70,7 +70,6 @@ __device__ __forceinline__ void list_insert(uint64_t* list, uint32_t mcap, uint6
 
 template <int DT, int METRIC>
 __global__ void __launch_bounds__(256) dense_topk_kernel(DenseArgs A) {
-  using acc_t = typename AccT<DT>::type;
   extern __shared__ __align__(16) uint8_t smem[];
   uint8_t* At = smem;                                   // [64][DT_SEG]
   uint8_t* Bt = At + DT_A * DT_SEG;                     // [64][DT_BSTRIDE]
@@ -129,9 +128,9 @@ __global__ void __launch_bounds__(256) dense_topk_kernel(DenseArgs A) {
       return A.points + id * A.pstride;
     };
     auto b_valid = [&]() -> uint32_t { return A.pstride; };
-    acc_t acc[DT_AW];
+    Acc<DT> acc[DT_AW];
 #pragma unroll
-    for (int a = 0; a < DT_AW; a++) acc[a] = 0;
+    for (int a = 0; a < DT_AW; a++) acc[a].clear();
     __syncthreads();          // previous tile's readers are done with Bt / Bid
     if (tid < DT_B) Bid[tid] = tid < (int)nb_tile ? (A.b_ids ? A.b_ids[bt + tid] : (uint32_t)(bt + tid)) : SENTINEL;
     for (uint32_t sg = 0; sg < nseg; sg++) {
@@ -141,11 +140,12 @@ __global__ void __launch_bounds__(256) dense_topk_kernel(DenseArgs A) {
       __syncthreads();
       const uint32_t nchunk = min((uint32_t)DT_SEG, A.pstride - sg * DT_SEG) / 16;
       for (uint32_t c = 0; c < nchunk; c++) {
-        const uint4 b = *reinterpret_cast<const uint4*>(Bt + (size_t)lane * DT_BSTRIDE + c * 16);
+        // the lane's B chunk is digested once (QReg); the 16 A chunks are LDS broadcasts
+        const QReg<DT> b = make_qreg<DT>(*reinterpret_cast<const uint4*>(Bt + (size_t)lane * DT_BSTRIDE + c * 16));
 #pragma unroll
         for (int a = 0; a < DT_AW; a++) {
           const uint4 q = *reinterpret_cast<const uint4*>(At + (size_t)(wave * DT_AW + a) * DT_SEG + c * 16);
-          dist_accum<DT, METRIC>(acc[a], b, q);
+          dist_accum<DT, METRIC>(acc[a], q, b);
         }
       }
     }
@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(256) dense_topk_kernel(DenseArgs A) {
       const uint32_t ar = wave * DT_AW + a;
       if (ar >= na_tile) break;               // uniform per wave
       uint64_t* list = lists + (size_t)ar * A.mcap;
-      const float dist = dist_finish<DT, METRIC>(acc[a]);
+      const float dist = dist_finish<DT, METRIC>(acc_lane_value<DT, METRIC>(acc[a]));
       const uint64_t key = make_key(dist, bid);
       bool ok = (lane < (int)nb_tile);
       if (A.exclude_same_id) ok = ok && (bid != Aid[ar]);
@@ -273,8 +273,8 @@ __global__ void __launch_bounds__(PANN_WAVE) query_distances_kernel(PointsView p
   uint4* qlds = reinterpret_cast<uint4*>(smem);
   const uint64_t qi = blockIdx.x;
   const uint8_t* qrow = q_ids ? pv.points + (uint64_t)q_ids[qi] * pv.pstride : q_ext + qi * q_stride;
-  uint4 qreg = make_uint4(0, 0, 0, 0);
-  load_query<LPC, NCH1>(qrow, q_ids ? pv.pstride : dbytes, pv.nch, qreg, qlds, lane);
+  QReg<DT> qreg{};
+  load_query<DT, LPC, NCH1>(qrow, q_ids ? pv.pstride : dbytes, pv.nch, qreg, qlds, lane);
   __syncthreads();
   const uint64_t j_lo = paired ? qi : 0, j_hi = paired ? qi + 1 : m;
   for (uint64_t j0 = j_lo; j0 < j_hi; j0 += PANN_WAVE) {

@@ -62,74 +62,147 @@ __device__ __forceinline__ T group_sum(T v) {
   return v;
 }
 
-// ---- distance accumulators.  One call consumes 16 bytes of a base row and the matching 16
-// bytes of the query.  Integer types are exact in int32 (euclidian_point.h:54-62,74-81;
-// mips_point.h:43-57); float types accumulate in f32 (lane-partial sums then a butterfly: the
-// summation ORDER differs from the CPU's left-to-right loop, see DESIGN.md "float order"). ----
-template <int DT>
-struct AccT { using type = int; };
-template <>
-struct AccT<PANN_F32> { using type = float; };
-template <>
-struct AccT<PANN_F16> { using type = float; };
-
+// ---- distance accumulators.  One dist_accum call consumes 16 bytes of a base row and the
+// matching 16 bytes of the query (held pre-digested in a QReg).  Integer types are exact in int32
+// (euclidian_point.h:54-62,74-81; mips_point.h:43-57); float types accumulate in f32: each lane
+// keeps two partial sums (even / odd elements), lanes are then combined by a butterfly, so the
+// summation ORDER differs from the CPU's left-to-right loop (DESIGN.md "float order"). ----
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+template <int DT> struct QReg;          // 16 query bytes, converted once per query
+template <> struct QReg<PANN_U8>  { uint4 raw; uint32_t qq; };   // qq = sum of squares of these 16 bytes
+template <> struct QReg<PANN_I8>  { uint4 raw; uint32_t qq; };
+template <> struct QReg<PANN_F32> { float f[4]; };
+template <> struct QReg<PANN_F16> { float f[8]; };
+
+template <int DT> struct Acc;           // per-lane partial state
+template <> struct Acc<PANN_U8>  { uint32_t aa, aq; __device__ __forceinline__ void clear() { aa = 0; aq = 0; } };
+template <> struct Acc<PANN_I8>  { int aa, aq;      __device__ __forceinline__ void clear() { aa = 0; aq = 0; } };
+template <> struct Acc<PANN_F32> { float2v s;       __device__ __forceinline__ void clear() { s = float2v{0.f, 0.f}; } };
+template <> struct Acc<PANN_F16> { float2v s;       __device__ __forceinline__ void clear() { s = float2v{0.f, 0.f}; } };
+
+template <int DT> struct AccT { using type = int; };             // type that crosses lanes
+template <> struct AccT<PANN_F32> { using type = float; };
+template <> struct AccT<PANN_F16> { using type = float; };
+
+template <int DT>
+__device__ __forceinline__ QReg<DT> make_qreg(const uint4& q) {
+  QReg<DT> r;
+  if constexpr (DT == PANN_U8) {
+    r.raw = q;
+    r.qq = __builtin_amdgcn_udot4(q.x, q.x, 0u, false);
+    r.qq = __builtin_amdgcn_udot4(q.y, q.y, r.qq, false);
+    r.qq = __builtin_amdgcn_udot4(q.z, q.z, r.qq, false);
+    r.qq = __builtin_amdgcn_udot4(q.w, q.w, r.qq, false);
+  } else if constexpr (DT == PANN_I8) {
+    r.raw = q;
+    int t = __builtin_amdgcn_sdot4((int)q.x, (int)q.x, 0, false);
+    t = __builtin_amdgcn_sdot4((int)q.y, (int)q.y, t, false);
+    t = __builtin_amdgcn_sdot4((int)q.z, (int)q.z, t, false);
+    t = __builtin_amdgcn_sdot4((int)q.w, (int)q.w, t, false);
+    r.qq = (uint32_t)t;
+  } else if constexpr (DT == PANN_F32) {
+    r.f[0] = __uint_as_float(q.x); r.f[1] = __uint_as_float(q.y);
+    r.f[2] = __uint_as_float(q.z); r.f[3] = __uint_as_float(q.w);
+  } else {
+    half8 h; __builtin_memcpy(&h, &q, 16);
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.f[i] = (float)h[i];
+  }
+  return r;
+}
+
+// q - (float)half(a, lo/hi): one v_fma_mix_f32 (f16 operand widened inside the FMA: a*(-1)+q, a
+// single rounding of the exact difference, i.e. bit-identical to cvt + sub)
+template <int HI>
+__device__ __forceinline__ float sub_widen_f16(uint32_t a_pair, float q) {
+  float t;
+  if constexpr (HI == 0)
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(t) : "v"(a_pair), "v"(q));
+  else
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t) : "v"(a_pair), "v"(q));
+  return t;
+}
+// acc + (float)half(a) * q   (MIPS term), same instruction
+template <int HI>
+__device__ __forceinline__ float fma_widen_f16(uint32_t a_pair, float q, float acc) {
+  float t;
+  if constexpr (HI == 0)
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(t) : "v"(a_pair), "v"(q), "v"(acc));
+  else
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t) : "v"(a_pair), "v"(q), "v"(acc));
+  return t;
+}
 
 template <int DT, int METRIC>
-__device__ __forceinline__ void dist_accum(typename AccT<DT>::type& acc, const uint4& a, const uint4& q) {
+__device__ __forceinline__ void dist_accum(Acc<DT>& acc, const uint4& a, const QReg<DT>& q) {
   if constexpr (DT == PANN_U8) {
-    // L2: sum (a-q)^2 = a.a - 2 a.q + q.q, all three as packed 4x8-bit dot products (exact)
-    const uint32_t av[4] = {a.x, a.y, a.z, a.w}, qv[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      if constexpr (METRIC == PANN_L2) {
-        uint32_t aa = __builtin_amdgcn_udot4(av[i], av[i], 0u, false);
-        uint32_t aq = __builtin_amdgcn_udot4(av[i], qv[i], 0u, false);
-        uint32_t qq = __builtin_amdgcn_udot4(qv[i], qv[i], 0u, false);
-        acc += (int)(aa + qq - 2u * aq);
-      } else {
-        acc += (int)__builtin_amdgcn_udot4(av[i], qv[i], 0u, false);
-      }
+    // L2: sum (a-q)^2 = a.a - 2 a.q + q.q as packed 4x8-bit dot products with accumulate (exact)
+    acc.aq = __builtin_amdgcn_udot4(a.x, q.raw.x, acc.aq, false);
+    acc.aq = __builtin_amdgcn_udot4(a.y, q.raw.y, acc.aq, false);
+    acc.aq = __builtin_amdgcn_udot4(a.z, q.raw.z, acc.aq, false);
+    acc.aq = __builtin_amdgcn_udot4(a.w, q.raw.w, acc.aq, false);
+    if constexpr (METRIC == PANN_L2) {
+      acc.aa = __builtin_amdgcn_udot4(a.x, a.x, acc.aa, false);
+      acc.aa = __builtin_amdgcn_udot4(a.y, a.y, acc.aa, false);
+      acc.aa = __builtin_amdgcn_udot4(a.z, a.z, acc.aa, false);
+      acc.aa = __builtin_amdgcn_udot4(a.w, a.w, acc.aa, false);
+      acc.aa += q.qq;
     }
   } else if constexpr (DT == PANN_I8) {
-    const int av[4] = {(int)a.x, (int)a.y, (int)a.z, (int)a.w}, qv[4] = {(int)q.x, (int)q.y, (int)q.z, (int)q.w};
+    acc.aq = __builtin_amdgcn_sdot4((int)a.x, (int)q.raw.x, acc.aq, false);
+    acc.aq = __builtin_amdgcn_sdot4((int)a.y, (int)q.raw.y, acc.aq, false);
+    acc.aq = __builtin_amdgcn_sdot4((int)a.z, (int)q.raw.z, acc.aq, false);
+    acc.aq = __builtin_amdgcn_sdot4((int)a.w, (int)q.raw.w, acc.aq, false);
+    if constexpr (METRIC == PANN_L2) {
+      acc.aa = __builtin_amdgcn_sdot4((int)a.x, (int)a.x, acc.aa, false);
+      acc.aa = __builtin_amdgcn_sdot4((int)a.y, (int)a.y, acc.aa, false);
+      acc.aa = __builtin_amdgcn_sdot4((int)a.z, (int)a.z, acc.aa, false);
+      acc.aa = __builtin_amdgcn_sdot4((int)a.w, (int)a.w, acc.aa, false);
+      acc.aa += (int)q.qq;
+    }
+  } else if constexpr (DT == PANN_F32) {
+    const float2v a01{__uint_as_float(a.x), __uint_as_float(a.y)}, a23{__uint_as_float(a.z), __uint_as_float(a.w)};
+    const float2v q01{q.f[0], q.f[1]}, q23{q.f[2], q.f[3]};
+    if constexpr (METRIC == PANN_L2) {
+      const float2v t01 = q01 - a01, t23 = q23 - a23;
+      acc.s = __builtin_elementwise_fma(t01, t01, acc.s);
+      acc.s = __builtin_elementwise_fma(t23, t23, acc.s);
+    } else {
+      acc.s = __builtin_elementwise_fma(q01, a01, acc.s);
+      acc.s = __builtin_elementwise_fma(q23, a23, acc.s);
+    }
+  } else {  // PANN_F16: halves widened to f32 inside the FMA (exact), arithmetic is f32
+    const uint32_t w[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       if constexpr (METRIC == PANN_L2) {
-        int aa = __builtin_amdgcn_sdot4(av[i], av[i], 0, false);
-        int aq = __builtin_amdgcn_sdot4(av[i], qv[i], 0, false);
-        int qq = __builtin_amdgcn_sdot4(qv[i], qv[i], 0, false);
-        acc += aa + qq - 2 * aq;
+        const float2v t{sub_widen_f16<0>(w[i], q.f[2 * i]), sub_widen_f16<1>(w[i], q.f[2 * i + 1])};
+        acc.s = __builtin_elementwise_fma(t, t, acc.s);
       } else {
-        acc += __builtin_amdgcn_sdot4(av[i], qv[i], 0, false);
+        acc.s = float2v{fma_widen_f16<0>(w[i], q.f[2 * i], acc.s.x), fma_widen_f16<1>(w[i], q.f[2 * i + 1], acc.s.y)};
       }
     }
-  } else if constexpr (DT == PANN_F32) {
-    const float av[4] = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w)};
-    const float qv[4] = {__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w)};
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      if constexpr (METRIC == PANN_L2) { float t = qv[i] - av[i]; acc = fmaf(t, t, acc); }
-      else acc = fmaf(qv[i], av[i], acc);
-    }
-  } else {  // PANN_F16: halves are widened to f32 first (exact), arithmetic is f32
-    half8 ah, qh;
-    __builtin_memcpy(&ah, &a, 16);
-    __builtin_memcpy(&qh, &q, 16);
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      float af = (float)ah[i], qf = (float)qh[i];
-      if constexpr (METRIC == PANN_L2) { float t = qf - af; acc = fmaf(t, t, acc); }
-      else acc = fmaf(qf, af, acc);
-    }
+  }
+}
+
+// the per-lane value that is summed across the lanes of a candidate group
+template <int DT, int METRIC>
+__device__ __forceinline__ typename AccT<DT>::type acc_lane_value(const Acc<DT>& acc) {
+  if constexpr (DT == PANN_U8) {
+    if constexpr (METRIC == PANN_L2) return (int)(acc.aa - 2u * acc.aq); else return (int)acc.aq;
+  } else if constexpr (DT == PANN_I8) {
+    if constexpr (METRIC == PANN_L2) return acc.aa - 2 * acc.aq; else return acc.aq;
+  } else {
+    return acc.s.x + acc.s.y;
   }
 }
 
 // final conversion to the reference's float distanceType (cast once for integers, negate for MIPS)
 template <int DT, int METRIC>
-__device__ __forceinline__ float dist_finish(typename AccT<DT>::type acc) {
-  float f = (float)acc;
+__device__ __forceinline__ float dist_finish(typename AccT<DT>::type tot) {
+  float f = (float)tot;
   if constexpr (METRIC == PANN_MIPS) f = -f;
   return f;
 }
@@ -156,58 +229,50 @@ __device__ __forceinline__ uint4 load16_guarded(const uint8_t* row, uint32_t off
 struct PointsView { const uint8_t* points; uint32_t pstride; uint32_t nch; };
 
 template <int DT, int METRIC, int LPC, bool NCH1, int U, typename Emit>
-__device__ __forceinline__ void gather_tile(const PointsView& PV, const uint4& qreg, const uint4* qlds,
+__device__ __forceinline__ void gather_tile(const PointsView& PV, const QReg<DT>& qreg, const uint4* qlds,
                                             const uint32_t* Pl, uint32_t m, int lane, Emit&& emit) {
-  using acc_t = typename AccT<DT>::type;
   constexpr int G = PANN_WAVE / LPC;
   const int grp = lane / LPC, sub = lane % LPC;
   for (uint32_t s0 = 0; s0 < m; s0 += G * U) {
-    acc_t acc[U];
+    Acc<DT> acc[U];
     uint32_t ids[U];
+    // groups past the end re-read the last candidate (a cache hit) instead of branching around the load
+#pragma unroll
+    for (int u = 0; u < U; u++) ids[u] = Pl[min(s0 + u * G + grp, m - 1)];
     if constexpr (NCH1) {
       uint4 v[U];
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        const uint32_t ci = s0 + u * G + grp;
-        ids[u] = ci < m ? Pl[ci] : SENTINEL;
-        v[u] = make_uint4(0, 0, 0, 0);
-        if (ci < m) v[u] = *reinterpret_cast<const uint4*>(PV.points + (uint64_t)ids[u] * PV.pstride + sub * 16);
-      }
+      for (int u = 0; u < U; u++)
+        v[u] = *reinterpret_cast<const uint4*>(PV.points + (uint64_t)ids[u] * PV.pstride + sub * 16);
 #pragma unroll
-      for (int u = 0; u < U; u++) { acc[u] = 0; dist_accum<DT, METRIC>(acc[u], v[u], qreg); }
+      for (int u = 0; u < U; u++) { acc[u].clear(); dist_accum<DT, METRIC>(acc[u], v[u], qreg); }
     } else {
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        const uint32_t ci = s0 + u * G + grp;
-        ids[u] = ci < m ? Pl[ci] : SENTINEL;
-        acc[u] = 0;
-      }
+      for (int u = 0; u < U; u++) acc[u].clear();
       for (uint32_t ch = 0; ch < PV.nch; ch++) {
         uint4 v[U];
-        const uint4 qv = qlds[ch * LPC + sub];
+        const QReg<DT> qv = make_qreg<DT>(qlds[ch * LPC + sub]);
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-          v[u] = make_uint4(0, 0, 0, 0);
-          if (ids[u] != SENTINEL)
-            v[u] = *reinterpret_cast<const uint4*>(PV.points + (uint64_t)ids[u] * PV.pstride + (ch * LPC + sub) * 16);
-        }
+        for (int u = 0; u < U; u++)
+          v[u] = *reinterpret_cast<const uint4*>(PV.points + (uint64_t)ids[u] * PV.pstride + (ch * LPC + sub) * 16);
 #pragma unroll
         for (int u = 0; u < U; u++) dist_accum<DT, METRIC>(acc[u], v[u], qv);
       }
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const acc_t tot = group_sum<LPC>(acc[u]);
+      const auto tot = group_sum<LPC>(acc_lane_value<DT, METRIC>(acc[u]));
       const float dist = dist_finish<DT, METRIC>(tot);
-      emit((sub == 0) && (ids[u] != SENTINEL), s0 + u * G + grp, ids[u], dist);
+      const uint32_t ci = s0 + u * G + grp;
+      emit((sub == 0) && (ci < m), ci, ids[u], dist);
     }
   }
 }
 
 // load one row (device layout, or an external query row of `valid` bytes) as the wave's query:
 // registers when NCH1, else LDS qlds[nch*LPC].  Caller syncs before using qlds.
-template <int LPC, bool NCH1>
-__device__ __forceinline__ void load_query(const uint8_t* qrow, uint32_t valid, uint32_t nch, uint4& qreg,
+template <int DT, int LPC, bool NCH1>
+__device__ __forceinline__ void load_query(const uint8_t* qrow, uint32_t valid, uint32_t nch, QReg<DT>& qreg,
                                            uint4* qlds, int lane) {
   const bool aligned = ((reinterpret_cast<uintptr_t>(qrow) & 15) == 0);
   auto fetch = [&](uint32_t j) -> uint4 {
@@ -218,7 +283,7 @@ __device__ __forceinline__ void load_query(const uint8_t* qrow, uint32_t valid, 
     uint4 v; __builtin_memcpy(&v, tmp, 16); return v;
   };
   if constexpr (NCH1) {
-    qreg = fetch(lane % LPC);
+    qreg = make_qreg<DT>(fetch(lane % LPC));
   } else {
     for (uint32_t j = lane; j < nch * LPC; j += PANN_WAVE) qlds[j] = fetch(j);
   }

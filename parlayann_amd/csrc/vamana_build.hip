@@ -51,8 +51,8 @@ __global__ void __launch_bounds__(PANN_WAVE) prune_keys_kernel(PruneArgs A) {
   extern __shared__ __align__(16) uint8_t smem[];
   uint4* qlds = reinterpret_cast<uint4*>(smem);
   const uint32_t p = A.owners[oi];
-  uint4 qreg = make_uint4(0, 0, 0, 0);
-  load_query<LPC, NCH1>(A.pv.points + (uint64_t)p * A.pv.pstride, A.dbytes, A.pv.nch, qreg, qlds, lane);
+  QReg<DT> qreg{};
+  load_query<DT, LPC, NCH1>(A.pv.points + (uint64_t)p * A.pv.pstride, A.dbytes, A.pv.nch, qreg, qlds, lane);
   __syncthreads();
   const uint64_t cb = A.cand_base[oi];
   const uint32_t cn = A.cand_cnt[oi];
@@ -147,9 +147,9 @@ __global__ void __launch_bounds__(PANN_WAVE) prune_greedy_kernel(GreedyArgs A) {
     if (lane == 0) Out[nsel] = ps;                  // :103
     nsel++;
     if (nsel == A.R) break;                          // the inner loop's kills can no longer matter
-    uint4 qreg = make_uint4(0, 0, 0, 0);
+    QReg<DT> qreg{};
     __syncthreads();
-    load_query<LPC, NCH1>(A.pv.points + (uint64_t)ps * A.pv.pstride, A.dbytes, A.pv.nch, qreg, qlds, lane);
+    load_query<DT, LPC, NCH1>(A.pv.points + (uint64_t)ps * A.pv.pstride, A.dbytes, A.pv.nch, qreg, qlds, lane);
     __syncthreads();
     for (uint32_t t0 = idx + 1; t0 < n; t0 += PANN_WAVE) {   // :105-115, 64 candidates at a time
       const uint32_t i = t0 + lane;
@@ -326,8 +326,8 @@ __global__ void __launch_bounds__(PANN_WAVE) sort_rows_kernel(PointsView pv, uin
   __shared__ uint64_t Kk[4096 + 64];
   extern __shared__ __align__(16) uint8_t smem[];
   uint4* qlds = reinterpret_cast<uint4*>(smem);
-  uint4 qreg = make_uint4(0, 0, 0, 0);
-  load_query<LPC, NCH1>(pv.points + (uint64_t)v * pv.pstride, dbytes, pv.nch, qreg, qlds, lane);
+  QReg<DT> qreg{};
+  load_query<DT, LPC, NCH1>(pv.points + (uint64_t)v * pv.pstride, dbytes, pv.nch, qreg, qlds, lane);
   __syncthreads();
   uint32_t* row = graph + (size_t)v * gstride;
   uint32_t deg = 0;
