@@ -144,6 +144,14 @@ int pann_pair_distances(pann_index* idx, const uint32_t* a_ids, const uint32_t* 
 int pann_query_distances(pann_index* idx, const void* queries, uint64_t nq, uint64_t q_stride_bytes,
                          const uint32_t* ids, uint64_t m, float* out);
 
+/* Re-scoring of beam_search_rerank (beamSearch.h:426-452): for query i the first cand_counts[i]
+ * (or c when cand_counts is NULL) ids of row i of cand_ids (nq x c) get their exact distance to
+ * query i.  resort != 0: sort by (dist,id) and keep k (:437-442); resort == 0: keep the first k in
+ * the given order (:447-452).  Unused output slots are 0xFFFFFFFF / +inf.  Host pointers. */
+int pann_rerank(pann_index* idx, const void* queries, uint64_t nq, uint64_t q_stride_bytes,
+                const uint32_t* cand_ids, uint32_t c, const uint32_t* cand_counts, uint32_t k, int resort,
+                uint32_t* out_ids, float* out_dists);
+
 /* ---- robustPrune (vamana/index.h:63-137) ---------------------------------------------------- */
 
 /* For each of m owners p_i: candidates = given list (ids, and dists to p_i; if cand_dists is NULL
@@ -186,6 +194,12 @@ int pann_leaf_knn(pann_index* idx, const uint32_t* ids, uint32_t N, uint32_t m, 
  * (total ids) x m. */
 int pann_leaf_knn_batch(pann_index* idx, const uint32_t* ids, const uint64_t* leaf_offsets,
                         uint64_t nleaves, uint32_t m, uint32_t* out_ids, float* out_dists);
+
+/* HCNNG cluster-tree split (clusterEdge.h:66-83): ids is the concatenation of nseg clusters
+ * (seg_offsets, nseg+1 entries); cluster s has pivots pivot_a[s], pivot_b[s];
+ * out_side[i] = 0 when d(ids[i], pivot_a) <= d(ids[i], pivot_b), else 1.  Host pointers. */
+int pann_pivot_split(pann_index* idx, const uint32_t* ids, const uint64_t* seg_offsets, uint64_t nseg,
+                     const uint32_t* pivot_a, const uint32_t* pivot_b, uint8_t* out_side);
 
 /* Brute-force k nearest base points for nq external queries (compute_groundtruth.cpp:22-59):
  * out rows sorted by (dist,id). Host pointers. */

@@ -559,4 +559,69 @@ double pann_oracle_recall(const uint32_t* result_ids, uint32_t res_stride, const
   return (double)hits / (double)(nq * k);
 }
 
+
+// ---- scalar quantisation ----
+// Euclidian_Point<uint8_t>::generate_parameters (euclidian_point.h:211-235); out2 = {slope, (float)offset}
+void pann_oracle_euclid_u8_params(const float* x, uint64_t n, uint32_t d, float* out2) {
+  float min_val = 0.0f, max_val = 0.0f;
+  bool all_ints = true;
+  for (uint64_t i = 0; i < n * d; i++) {
+    float v = x[i];
+    all_ints = all_ints && (v >= 0) && (v - (long)v) == 0;
+    min_val = std::min(min_val, v); max_val = std::max(max_val, v);
+  }
+  if (all_ints) { if (max_val < 256) max_val = 255; min_val = 0; }
+  const long range = 255;
+  float slope = range / (max_val - min_val);                       // :106
+  int32_t offset = (int32_t)std::round(min_val * slope);           // :107
+  out2[0] = slope; out2[1] = (float)offset;
+}
+// Euclidian_Point<uint8_t>::translate_point (euclidian_point.h:182-209)
+void pann_oracle_euclid_u8_translate(const float* x, uint64_t n, uint32_t d, float slope, int32_t offset, uint8_t* out) {
+  const long range = 255;
+  for (uint64_t i = 0; i < n * d; i++) {
+    if (slope == 1.0 && offset == 0) { out[i] = (uint8_t)x[i]; continue; }
+    int64_t r = (int64_t)(std::round(x[i] * slope)) - offset;
+    if (r < 0) r = 0;
+    if (r > range) r = range;
+    out[i] = (uint8_t)r;
+  }
+}
+// Mips_Point<float>::normalize (mips_point.h:113-122)
+void pann_oracle_normalize(float* x, uint64_t n, uint32_t d) {
+  for (uint64_t i = 0; i < n; i++) {
+    float* v = x + i * d;
+    double norm = 0.0;
+    for (uint32_t j = 0; j < d; j++) norm += v[j] * v[j];
+    norm = std::sqrt(norm);
+    if (norm == 0) norm = 1.0;
+    float inv_norm = 1.0 / norm;
+    for (uint32_t j = 0; j < d; j++) v[j] = v[j] * inv_norm;
+  }
+}
+// Quantized_Mips_Point<8,trim>::generate_parameters (mips_point.h:433-486) -> max_val
+float pann_oracle_mips_i8_maxval(const float* x, uint64_t n, uint32_t d, int trim) {
+  long len = (long)(n * d);
+  std::vector<float> vals(x, x + len);
+  std::sort(vals.begin(), vals.end());
+  float min_val, max_val;
+  if (trim) {
+    float cutoff = .0001;
+    min_val = vals[(long)(cutoff * len)];
+    max_val = vals[(long)((1.0 - cutoff) * (len - 1))];
+  } else { min_val = vals[0]; max_val = vals[len - 1]; }
+  return std::max(max_val, -min_val);
+}
+// Quantized_Mips_Point<8>::translate_point (mips_point.h:416-430), range = 255
+void pann_oracle_mips_i8_translate(const float* x, uint64_t n, uint32_t d, float mv, int8_t* out) {
+  const int range = 255;
+  for (uint64_t i = 0; i < n * d; i++) {
+    float scale = (range / 2) / mv;
+    float pj = x[i];
+    if (pj < -mv) out[i] = (int8_t)(-range / 2);
+    else if (pj > mv) out[i] = (int8_t)(range / 2);
+    else { int32_t v = std::round(pj * scale); out[i] = (int8_t)v; }
+  }
+}
+
 }  // extern "C"

@@ -78,6 +78,9 @@ SIGNATURES = {
     "pann_leaf_knn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "pann_leaf_knn_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
                                       C.c_void_p]),
+    "pann_rerank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p,
+                              C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
+    "pann_pivot_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pann_bruteforce_knn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p,
                                       C.c_void_p]),
 }

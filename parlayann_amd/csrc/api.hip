@@ -570,4 +570,76 @@ int pann_bruteforce_knn(pann_index* idx, const void* queries, uint64_t nq, uint6
   return PANN_OK;
 }
 
+
+int pann_pivot_split(pann_index* idx, const uint32_t* ids, const uint64_t* seg_offsets, uint64_t nseg,
+                     const uint32_t* pivot_a, const uint32_t* pivot_b, uint8_t* out_side) {
+  if (int rc = check_idx(idx, "pann_pivot_split")) return rc;
+  if (nseg == 0) return PANN_OK;
+  if (!ids || !seg_offsets || !pivot_a || !pivot_b || !out_side) { set_error("pann_pivot_split: null argument"); return PANN_ERR_BAD_ARG; }
+  const uint64_t total = seg_offsets[nseg];
+  if (total == 0) return PANN_OK;
+  for (uint64_t i = 0; i < total; i++)
+    if (ids[i] >= idx->ix.n) { set_error("pann_pivot_split: id out of range"); return PANN_ERR_BAD_ARG; }
+  std::vector<uint32_t> tseg, tcnt; std::vector<uint64_t> tlo;
+  for (uint64_t s = 0; s < nseg; s++) {
+    if (pivot_a[s] >= idx->ix.n || pivot_b[s] >= idx->ix.n) { set_error("pann_pivot_split: pivot out of range"); return PANN_ERR_BAD_ARG; }
+    for (uint64_t a = seg_offsets[s]; a < seg_offsets[s + 1]; a += 64) {
+      tseg.push_back((uint32_t)s); tlo.push_back(a); tcnt.push_back((uint32_t)std::min<uint64_t>(64, seg_offsets[s + 1] - a));
+    }
+  }
+  DeviceGuard g(idx->device);
+  hipStream_t st = idx->stream;
+  const size_t nt = tseg.size();
+  if (int rc = idx->stage[2].ensure(total * 4)) return rc;
+  if (int rc = idx->stage[3].ensure(nt * 8)) return rc;
+  if (int rc = idx->stage[4].ensure(nt * 4)) return rc;
+  if (int rc = idx->stage[5].ensure(nt * 4)) return rc;
+  if (int rc = idx->stage[6].ensure(nseg * 4)) return rc;
+  if (int rc = idx->stage[7].ensure(nseg * 4)) return rc;
+  if (int rc = idx->stage[8].ensure(total)) return rc;
+  PANN_HIP(hipMemcpyAsync(idx->stage[2].p, ids, total * 4, hipMemcpyHostToDevice, st));
+  PANN_HIP(hipMemcpyAsync(idx->stage[3].p, tlo.data(), nt * 8, hipMemcpyHostToDevice, st));
+  PANN_HIP(hipMemcpyAsync(idx->stage[4].p, tseg.data(), nt * 4, hipMemcpyHostToDevice, st));
+  PANN_HIP(hipMemcpyAsync(idx->stage[5].p, tcnt.data(), nt * 4, hipMemcpyHostToDevice, st));
+  PANN_HIP(hipMemcpyAsync(idx->stage[6].p, pivot_a, nseg * 4, hipMemcpyHostToDevice, st));
+  PANN_HIP(hipMemcpyAsync(idx->stage[7].p, pivot_b, nseg * 4, hipMemcpyHostToDevice, st));
+  if (int rc = pivot_split_dev(idx->ix, st, idx->stage[2].as<uint32_t>(), idx->stage[4].as<uint32_t>(), idx->stage[3].as<uint64_t>(),
+                               idx->stage[5].as<uint32_t>(), (uint32_t)nt, idx->stage[6].as<uint32_t>(), idx->stage[7].as<uint32_t>(),
+                               idx->stage[8].as<uint8_t>())) return rc;
+  PANN_HIP(hipMemcpyAsync(out_side, idx->stage[8].p, total, hipMemcpyDeviceToHost, st));
+  PANN_HIP(hipStreamSynchronize(st));
+  return PANN_OK;
+}
+
+
+int pann_rerank(pann_index* idx, const void* queries, uint64_t nq, uint64_t q_stride_bytes, const uint32_t* cand_ids,
+                uint32_t c, const uint32_t* cand_counts, uint32_t k, int resort, uint32_t* out_ids, float* out_dists) {
+  if (int rc = check_idx(idx, "pann_rerank")) return rc;
+  if (nq == 0) return PANN_OK;
+  if (!queries || !cand_ids || !out_ids || !out_dists || k == 0) { set_error("pann_rerank: null argument"); return PANN_ERR_BAD_ARG; }
+  if (q_stride_bytes < idx->ix.dbytes) { set_error("pann_rerank: query stride smaller than a row"); return PANN_ERR_BAD_ARG; }
+  for (uint64_t i = 0; i < nq; i++) {
+    const uint32_t cn = cand_counts ? std::min(cand_counts[i], c) : c;
+    for (uint32_t j = 0; j < cn; j++)
+      if (cand_ids[i * c + j] >= idx->ix.n) { set_error("pann_rerank: candidate id out of range"); return PANN_ERR_BAD_ARG; }
+  }
+  DeviceGuard g(idx->device);
+  hipStream_t st = idx->stream;
+  if (int rc = idx->stage[2].ensure(nq * q_stride_bytes + 16)) return rc;
+  if (int rc = idx->stage[3].ensure(nq * c * 4)) return rc;
+  if (int rc = idx->stage[4].ensure(nq * 4)) return rc;
+  if (int rc = idx->stage[6].ensure(nq * k * 4)) return rc;
+  if (int rc = idx->stage[7].ensure(nq * k * 4)) return rc;
+  PANN_HIP(hipMemcpyAsync(idx->stage[2].p, queries, (nq - 1) * q_stride_bytes + idx->ix.dbytes, hipMemcpyHostToDevice, st));
+  PANN_HIP(hipMemcpyAsync(idx->stage[3].p, cand_ids, nq * c * 4, hipMemcpyHostToDevice, st));
+  if (cand_counts) PANN_HIP(hipMemcpyAsync(idx->stage[4].p, cand_counts, nq * 4, hipMemcpyHostToDevice, st));
+  if (int rc = rerank_dev(idx->ix, st, idx->stage[2].as<uint8_t>(), q_stride_bytes, nq, idx->stage[3].as<uint32_t>(), c,
+                          cand_counts ? idx->stage[4].as<uint32_t>() : nullptr, k, resort, idx->stage[6].as<uint32_t>(),
+                          idx->stage[7].as<float>())) return rc;
+  PANN_HIP(hipMemcpyAsync(out_ids, idx->stage[6].p, nq * k * 4, hipMemcpyDeviceToHost, st));
+  PANN_HIP(hipMemcpyAsync(out_dists, idx->stage[7].p, nq * k * 4, hipMemcpyDeviceToHost, st));
+  PANN_HIP(hipStreamSynchronize(st));
+  return PANN_OK;
+}
+
 }  // extern "C"

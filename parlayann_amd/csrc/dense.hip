@@ -302,4 +302,98 @@ int query_distances_dev(const DeviceIndex& ix, hipStream_t st, const uint8_t* d_
   return PANN_OK;
 }
 
+// HCNNG two-pivot split (clusterEdge.h:66-83): one wave per tile of <=64 cluster members; the two
+// pivots are the wave's queries in turn, the members are the gathered candidates.
+template <int DT, int METRIC, int LPC, bool NCH1>
+__global__ void __launch_bounds__(PANN_WAVE) pivot_split_kernel(PointsView pv, uint32_t dbytes, const uint32_t* ids,
+                                                                const uint32_t* tile_seg, const uint64_t* tile_lo,
+                                                                const uint32_t* tile_cnt, const uint32_t* pivot_a,
+                                                                const uint32_t* pivot_b, uint8_t* out_side) {
+  const int lane = threadIdx.x;
+  __shared__ uint32_t Pl[PANN_WAVE];
+  __shared__ float Da[PANN_WAVE];
+  extern __shared__ __align__(16) uint8_t smem[];
+  uint4* qlds = reinterpret_cast<uint4*>(smem);
+  const uint32_t t = blockIdx.x;
+  const uint32_t seg = tile_seg[t];
+  const uint64_t lo = tile_lo[t];
+  const uint32_t mm = tile_cnt[t];
+  if (lane < (int)mm) Pl[lane] = ids[lo + lane];
+  QReg<DT> qreg{};
+  load_query<DT, LPC, NCH1>(pv.points + (uint64_t)pivot_a[seg] * pv.pstride, pv.pstride, pv.nch, qreg, qlds, lane);
+  __syncthreads();
+  gather_tile<DT, METRIC, LPC, NCH1, 4>(pv, qreg, qlds, Pl, mm, lane,
+    [&](bool has, uint32_t ci, uint32_t, float dist) { if (has) Da[ci] = dist; });
+  __syncthreads();
+  load_query<DT, LPC, NCH1>(pv.points + (uint64_t)pivot_b[seg] * pv.pstride, pv.pstride, pv.nch, qreg, qlds, lane);
+  __syncthreads();
+  gather_tile<DT, METRIC, LPC, NCH1, 4>(pv, qreg, qlds, Pl, mm, lane,
+    [&](bool has, uint32_t ci, uint32_t, float dist) { if (has) out_side[lo + ci] = (Da[ci] <= dist) ? 0 : 1; });
+}
+
+int pivot_split_dev(const DeviceIndex& ix, hipStream_t st, const uint32_t* d_ids, const uint32_t* d_tile_seg,
+                    const uint64_t* d_tile_lo, const uint32_t* d_tile_cnt, uint32_t ntiles, const uint32_t* d_pa,
+                    const uint32_t* d_pb, uint8_t* d_side) {
+  if (ntiles == 0) return PANN_OK;
+  const PointsView pv{ix.points, ix.pstride, ix.nch};
+  const size_t qb = ix.nch == 1 ? 0 : (size_t)ix.nch * ix.lpc * 16;
+#define CALL_PS(DT, MT, L, N1) hipLaunchKernelGGL((pivot_split_kernel<DT, MT, L, N1>), dim3(ntiles), dim3(PANN_WAVE), qb, st, pv, ix.dbytes, d_ids, d_tile_seg, d_tile_lo, d_tile_cnt, d_pa, d_pb, d_side)
+  PANN_TYPE_SWITCH(ix, CALL_PS);
+#undef CALL_PS
+  PANN_HIP(hipGetLastError());
+  return PANN_OK;
+}
+
+// beam_search_rerank's re-scoring (beamSearch.h:426-452): one wave per query
+template <int DT, int METRIC, int LPC, bool NCH1>
+__global__ void __launch_bounds__(PANN_WAVE) rerank_kernel(PointsView pv, uint32_t dbytes, const uint8_t* q_ext,
+                                                           uint64_t q_stride, const uint32_t* cand_ids, uint32_t c,
+                                                           const uint32_t* cand_counts, uint32_t k, int resort,
+                                                           uint32_t* out_ids, float* out_dists) {
+  const int lane = threadIdx.x;
+  __shared__ uint32_t Pl[PANN_WAVE];
+  extern __shared__ __align__(16) uint8_t smem[];
+  uint64_t* K = reinterpret_cast<uint64_t*>(smem);                  // [c] keys
+  uint4* qlds = reinterpret_cast<uint4*>(K + ((c + 1) & ~1u));
+  const uint64_t qi = blockIdx.x;
+  QReg<DT> qreg{};
+  load_query<DT, LPC, NCH1>(q_ext + qi * q_stride, dbytes, pv.nch, qreg, qlds, lane);
+  __syncthreads();
+  const uint32_t cn = cand_counts ? min(cand_counts[qi], c) : c;
+  const uint32_t* ids = cand_ids + qi * c;
+  for (uint32_t j0 = 0; j0 < cn; j0 += PANN_WAVE) {
+    const uint32_t mm = min(cn - j0, (uint32_t)PANN_WAVE);
+    if (lane < (int)mm) Pl[lane] = ids[j0 + lane];
+    __syncthreads();
+    gather_tile<DT, METRIC, LPC, NCH1, 4>(pv, qreg, qlds, Pl, mm, lane,
+      [&](bool has, uint32_t ci, uint32_t id, float dist) { if (has) K[j0 + ci] = make_key(dist, id); });
+    __syncthreads();
+  }
+  for (uint32_t j0 = 0; j0 < max(cn, k); j0 += PANN_WAVE) {
+    const uint32_t j = j0 + lane;
+    if (j < cn) {
+      const uint64_t key = K[j];
+      uint32_t r = j;
+      if (resort) { r = 0; for (uint32_t i = 0; i < cn; i++) { const uint64_t o = K[i]; r += (o < key || (o == key && i < j)) ? 1u : 0u; } }
+      if (r < k) { out_ids[qi * k + r] = key_id(key); out_dists[qi * k + r] = key_dist(key); }
+    } else if (j < k) {
+      out_ids[qi * k + j] = SENTINEL; out_dists[qi * k + j] = __builtin_inff();
+    }
+  }
+}
+
+int rerank_dev(const DeviceIndex& ix, hipStream_t st, const uint8_t* d_q, uint64_t q_stride, uint64_t nq,
+               const uint32_t* d_cand, uint32_t c, const uint32_t* d_cnt, uint32_t k, int resort, uint32_t* d_out_ids,
+               float* d_out_dists) {
+  if (nq == 0) return PANN_OK;
+  if (c == 0 || c > 4096) { set_error("pann_rerank: candidates per query must be in [1,4096]"); return PANN_ERR_BAD_ARG; }
+  const PointsView pv{ix.points, ix.pstride, ix.nch};
+  const size_t lds = (size_t)((c + 1) & ~1u) * 8 + (ix.nch == 1 ? 0 : (size_t)ix.nch * ix.lpc * 16);
+#define CALL_RR(DT, MT, L, N1) hipLaunchKernelGGL((rerank_kernel<DT, MT, L, N1>), dim3((uint32_t)nq), dim3(PANN_WAVE), lds, st, pv, ix.dbytes, d_q, q_stride, d_cand, c, d_cnt, k, resort, d_out_ids, d_out_dists)
+  PANN_TYPE_SWITCH(ix, CALL_RR);
+#undef CALL_RR
+  PANN_HIP(hipGetLastError());
+  return PANN_OK;
+}
+
 }  // namespace pann

@@ -76,4 +76,12 @@ int query_distances_dev(const DeviceIndex& ix, hipStream_t st, const uint8_t* d_
                         const uint32_t* d_q_ids, uint64_t nq, const uint32_t* d_ids, uint64_t m, int paired,
                         float* d_out);
 
+int pivot_split_dev(const DeviceIndex& ix, hipStream_t st, const uint32_t* d_ids, const uint32_t* d_tile_seg,
+                    const uint64_t* d_tile_lo, const uint32_t* d_tile_cnt, uint32_t ntiles, const uint32_t* d_pa,
+                    const uint32_t* d_pb, uint8_t* d_side);
+
+int rerank_dev(const DeviceIndex& ix, hipStream_t st, const uint8_t* d_q, uint64_t q_stride, uint64_t nq,
+               const uint32_t* d_cand, uint32_t c, const uint32_t* d_cnt, uint32_t k, int resort, uint32_t* d_out_ids,
+               float* d_out_dists);
+
 }  // namespace pann

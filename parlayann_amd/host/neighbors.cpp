@@ -1,0 +1,78 @@
+// neighbors.cpp -- example driver with the reference CLI's flag names (algorithms/bench/neighborsTime.C
+// :80-121): builds (Vamana or HCNNG) or loads a graph, runs the fixed-beam query of the `-Q` path
+// (check_nn_recall.h:221-226) and prints recall / QPS.  Flags: -base_path -query_path -gt_path
+// -graph_path -graph_outfile -data_type {uint8,int8,float} -dist_func {Euclidian,mips} -k -Q -R -L
+// -alpha -num_passes -cluster_size -mst_deg -num_clusters -alg {vamana,hcnng} -device -seed
+#include <cstring>
+#include <map>
+#include <string>
+
+#include "check_nn_recall.h"
+#include "hcnng_index.h"
+#include "vamana_index.h"
+
+using namespace parlayANN;
+using indexType = unsigned int;
+
+struct Args {
+  std::map<std::string, std::string> kv;
+  Args(int argc, char** argv) { for (int i = 1; i + 1 < argc; i += 2) kv[argv[i]] = argv[i + 1]; }
+  const char* str(const char* k) const { auto it = kv.find(k); return it == kv.end() ? nullptr : it->second.c_str(); }
+  long num(const char* k, long d) const { auto s = str(k); return s ? atol(s) : d; }
+  double flt(const char* k, double d) const { auto s = str(k); return s ? atof(s) : d; }
+};
+
+template <class Point>
+int run(const Args& a) {
+  using PR = PointRange<Point>;
+  const char* base = a.str("-base_path");
+  if (!base) { std::cout << "usage: neighbors -base_path <b> [-graph_path <g>] [-query_path <q> -gt_path <gt>] ..." << std::endl; return 1; }
+  PR Points(base);
+  const std::string alg = a.str("-alg") ? a.str("-alg") : "vamana";
+  const long k = a.num("-k", 10), Q = a.num("-Q", 64);
+  BuildParams BP;
+  if (alg == "hcnng") BP = BuildParams(a.num("-num_clusters", 30), a.num("-cluster_size", 1000), a.num("-mst_deg", 3));
+  else BP = BuildParams(a.num("-R", 64), a.num("-L", 128), a.flt("-alpha", 1.2), (int)a.num("-num_passes", 1));
+  Graph<indexType> G;
+  if (a.str("-graph_path")) {
+    G = Graph<indexType>(a.str("-graph_path"));
+  } else {
+    G = Graph<indexType>(BP.max_degree(), Points.size());
+    const auto t0 = std::chrono::steady_clock::now();
+    if (alg == "hcnng") {
+      hcnng_index<Point, PR, indexType> I; I.seed = (uint64_t)a.num("-seed", 1);
+      I.build_index(G, Points, BP.num_clusters, BP.cluster_size, BP.MST_deg);
+      std::cout << "tree time: " << I.t_tree_s << " leaf knn time: " << I.t_leaf_s << " mst time: " << I.t_mst_s << std::endl;
+    } else {
+      knn_index<PR, indexType> I(BP); I.seed = (uint64_t)a.num("-seed", 1);
+      stats<indexType> BuildStats(Points.size());
+      I.build_index(G, Points, BuildStats);
+    }
+    std::cout << "ANN: " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << std::endl;
+    if (a.str("-graph_outfile")) G.save(a.str("-graph_outfile"));
+  }
+  size_t tot = 0, mx = 0;
+  for (size_t i = 0; i < G.size(); i++) { tot += G[(indexType)i].size(); mx = std::max(mx, G[(indexType)i].size()); }
+  std::cout << "Graph has average degree " << (double)tot / G.size() << " and maximum degree " << mx << std::endl;
+  if (a.str("-query_path")) {
+    PR Queries(a.str("-query_path"));
+    groundTruth<indexType> GT(a.str("-gt_path"));
+    DeviceIndex<PR, indexType> DI(Points, &G, 0, (int)a.num("-device", 0));
+    QueryParams QP(k, Q, 1.35, (long)G.size(), (long)G.max_degree());   // check_nn_recall.h:219,224
+    for (int rep = 0; rep < 5; rep++) checkRecall<PR, indexType>(DI, Queries, GT, 0, k, QP, true);   // :221-226
+  }
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  Args a(argc, argv);
+  const std::string dt = a.str("-data_type") ? a.str("-data_type") : "uint8";
+  const std::string df = a.str("-dist_func") ? a.str("-dist_func") : "Euclidian";
+  if (df != "Euclidian" && df != "mips") { std::cout << "Error: specify distance type Euclidian or mips" << std::endl; abort(); }
+  const bool mips = df == "mips";
+  if (dt == "uint8") return mips ? run<Mips_Point<uint8_t>>(a) : run<Euclidian_Point<uint8_t>>(a);
+  if (dt == "int8") return mips ? run<Mips_Point<int8_t>>(a) : run<Euclidian_Point<int8_t>>(a);
+  if (dt == "float") return mips ? run<Mips_Point<float>>(a) : run<Euclidian_Point<float>>(a);
+  std::cout << "Error: data type not specified correctly, specify int8, uint8, or float" << std::endl;   // neighborsTime.C:143-150
+  abort();
+}

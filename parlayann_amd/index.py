@@ -181,3 +181,22 @@ class DeviceIndex:
         oi = np.empty((len(q), k), np.uint32); od = np.empty((len(q), k), np.float32)
         check(self._lib.pann_bruteforce_knn(self._h, _ptr(q), len(q), q.strides[0], k, _ptr(oi), _ptr(od)))
         return oi, od
+
+    def pivot_split(self, ids, seg_offsets, pivot_a, pivot_b):
+        """clusterEdge.h:66-83: side 0 when d(id, pivot_a) <= d(id, pivot_b)."""
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        off = np.ascontiguousarray(seg_offsets, dtype=np.uint64)
+        pa = np.ascontiguousarray(pivot_a, dtype=np.uint32); pb = np.ascontiguousarray(pivot_b, dtype=np.uint32)
+        side = np.empty(len(ids), np.uint8)
+        check(self._lib.pann_pivot_split(self._h, _ptr(ids), _ptr(off), len(off) - 1, _ptr(pa), _ptr(pb), _ptr(side)))
+        return side
+
+    def rerank(self, queries, cand_ids, cand_counts, k, resort=True):
+        """beamSearch.h:426-452: exact distances of each query's candidates, (re)sorted, first k."""
+        q = np.ascontiguousarray(queries)
+        cand = np.ascontiguousarray(cand_ids, dtype=np.uint32)
+        cnt = None if cand_counts is None else np.ascontiguousarray(cand_counts, dtype=np.uint32)
+        oi = np.empty((len(q), k), np.uint32); od = np.empty((len(q), k), np.float32)
+        check(self._lib.pann_rerank(self._h, _ptr(q), len(q), q.strides[0], _ptr(cand), cand.shape[1], _ptr(cnt), k,
+                                    1 if resort else 0, _ptr(oi), _ptr(od)))
+        return oi, od

@@ -31,6 +31,7 @@ def load():
         _lib.pann_oracle_hash64_2.restype = C.c_uint64
         _lib.pann_oracle_hash64_2.argtypes = [C.c_uint64]
         _lib.pann_oracle_recall.restype = C.c_double
+        _lib.pann_oracle_mips_i8_maxval.restype = C.c_float
     return Oracle(_lib)
 
 
@@ -169,3 +170,30 @@ class Oracle:
         g = np.ascontiguousarray(gt_ids, dtype=np.uint32); gd = np.ascontiguousarray(gt_dists, dtype=np.float32)
         return float(self.lib.pann_oracle_recall(_p(r), C.c_uint32(r.shape[1]), _p(g), _p(gd),
                                                  C.c_uint32(g.shape[1]), C.c_uint64(len(r)), C.c_uint32(k)))
+
+    # ---- quantisation ----
+    def euclid_u8_params(self, x):
+        x = np.ascontiguousarray(x, np.float32); out = np.zeros(2, np.float32)
+        self.lib.pann_oracle_euclid_u8_params(_p(x), C.c_uint64(x.shape[0]), C.c_uint32(x.shape[1]), _p(out))
+        return np.float32(out[0]), int(out[1])
+
+    def euclid_u8_translate(self, x, slope, offset):
+        x = np.ascontiguousarray(x, np.float32); out = np.empty(x.shape, np.uint8)
+        self.lib.pann_oracle_euclid_u8_translate(_p(x), C.c_uint64(x.shape[0]), C.c_uint32(x.shape[1]), C.c_float(slope),
+                                                 C.c_int32(offset), _p(out))
+        return out
+
+    def normalize(self, x):
+        x = np.array(x, np.float32, copy=True, order="C")
+        self.lib.pann_oracle_normalize(_p(x), C.c_uint64(x.shape[0]), C.c_uint32(x.shape[1]))
+        return x
+
+    def mips_i8_maxval(self, x, trim=True):
+        x = np.ascontiguousarray(x, np.float32)
+        return np.float32(self.lib.pann_oracle_mips_i8_maxval(_p(x), C.c_uint64(x.shape[0]), C.c_uint32(x.shape[1]),
+                                                              C.c_int(1 if trim else 0)))
+
+    def mips_i8_translate(self, x, mv):
+        x = np.ascontiguousarray(x, np.float32); out = np.empty(x.shape, np.int8)
+        self.lib.pann_oracle_mips_i8_translate(_p(x), C.c_uint64(x.shape[0]), C.c_uint32(x.shape[1]), C.c_float(mv), _p(out))
+        return out

@@ -1,0 +1,103 @@
+"""The C++ host mirror (parlayann_amd/host/*.h) driven through its example CLI `neighbors`:
+file formats, knn_index::build_index, hcnng_index::build_index, checkRecall -- all over the C-ABI."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from parlayann_amd import DeviceIndex, datasets, io
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "parlayann_amd", "host")
+
+
+@pytest.fixture(scope="module")
+def exe():
+    subprocess.check_call(["make", "-C", HOST, "-s"])
+    return os.path.join(HOST, "neighbors")
+
+
+@pytest.fixture(scope="module")
+def files(tmp_path_factory, oracle):
+    d = tmp_path_factory.mktemp("data")
+    X = datasets.sift_like(8000, 128, seed=1234, dtype=np.uint8)
+    Q = datasets.sift_like(200, 128, seed=4321, dtype=np.uint8)
+    gt, gd = oracle.bruteforce_knn(X, Q, 100)
+    io.write_bin(d / "base.bin", X); io.write_bin(d / "query.bin", Q); io.write_ibin(d / "gt.ibin", gt, gd)
+    return d, X, Q, gt, gd
+
+
+def _run(exe, *args):
+    out = subprocess.run([exe, *[str(a) for a in args]], check=True, capture_output=True, text=True).stdout
+    return out
+
+
+def test_vamana_cli_builds_the_same_graph_and_reports_recall(exe, files, oracle):
+    d, X, Q, gt, gd = files
+    out = _run(exe, "-base_path", d / "base.bin", "-query_path", d / "query.bin", "-gt_path", d / "gt.ibin",
+               "-graph_outfile", d / "g.graph", "-data_type", "uint8", "-dist_func", "Euclidian", "-R", 32, "-L", 64,
+               "-alpha", 1.2, "-num_passes", 1, "-k", 10, "-Q", 64, "-seed", 5)
+    G = io.read_graph(d / "g.graph")
+    Go, _ = oracle.vamana_build(X, 32, 64, 1.2, num_passes=1, seed=5)
+    cols = np.arange(32)[None, :]
+    np.testing.assert_array_equal(G[:, 0], Go[:, 0])
+    np.testing.assert_array_equal(np.where(cols < G[:, :1], G[:, 1:], 0), np.where(cols < Go[:, :1], Go[:, 1:], 0))
+    rec = [float(m) for m in re.findall(r"recall=([0-9.]+)", out)]
+    assert len(rec) == 5
+    o = oracle.batch_search(X, Go, queries=Q, k=10, beam=64)
+    assert abs(rec[0] - oracle.recall(o["ids"], gt, gd, 10)) < 1e-6
+    vis = int(re.findall(r"visited=([0-9]+)", out)[0]); cm = int(re.findall(r"comparisons=([0-9]+)", out)[0])
+    assert vis == int(o["visited_count"].astype(np.uint64).sum() // len(Q))
+    assert cm == int(o["dist_cmps"].astype(np.uint64).sum() // len(Q))
+    # prebuilt-graph path (-graph_path) gives the same answers
+    out2 = _run(exe, "-base_path", d / "base.bin", "-query_path", d / "query.bin", "-gt_path", d / "gt.ibin",
+                "-graph_path", d / "g.graph", "-data_type", "uint8", "-k", 10, "-Q", 64)
+    assert re.findall(r"recall=([0-9.]+)", out2)[0] == re.findall(r"recall=([0-9.]+)", out)[0]
+
+
+def test_hcnng_cli_graph_quality(exe, files):
+    d, X, Q, gt, gd = files
+    out = _run(exe, "-base_path", d / "base.bin", "-query_path", d / "query.bin", "-gt_path", d / "gt.ibin",
+               "-graph_outfile", d / "h.graph", "-alg", "hcnng", "-data_type", "uint8", "-num_clusters", 12,
+               "-cluster_size", 300, "-mst_deg", 3, "-k", 10, "-Q", 64, "-seed", 3)
+    G = io.read_graph(d / "h.graph")
+    assert G.shape[1] - 1 == 36 and G[:, 0].max() <= 36 and G[:, 0].min() >= 1
+    rec = [float(m) for m in re.findall(r"recall=([0-9.]+)", out)]
+    assert rec and rec[0] > 0.9, out[-400:]
+    # every edge is symmetric at insertion (hcnng_index.h:213-216) and no vertex links to itself
+    nb = [set(G[i, 1:1 + G[i, 0]].tolist()) for i in range(len(G))]
+    assert all(i not in nb[i] for i in range(len(G)))
+    asym = sum(1 for i in range(0, len(G), 7) for j in nb[i] if i not in nb[j])
+    assert asym == 0
+    # deterministic given the seed
+    _run(exe, "-base_path", d / "base.bin", "-graph_outfile", d / "h2.graph", "-alg", "hcnng", "-data_type", "uint8",
+         "-num_clusters", 12, "-cluster_size", 300, "-mst_deg", 3, "-seed", 3)
+    np.testing.assert_array_equal(G, io.read_graph(d / "h2.graph"))
+
+
+def test_pivot_split_matches_oracle_distances(oracle):
+    X = datasets.sift_like(3000, 96, seed=1, dtype=np.float32)
+    ix = DeviceIndex(X, max_degree=8)
+    rng = np.random.default_rng(0)
+    sizes = [700, 64, 1, 130]
+    ids = np.concatenate([rng.choice(len(X), s, replace=False) for s in sizes]).astype(np.uint32)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    pa = rng.integers(0, len(X), len(sizes)).astype(np.uint32); pb = rng.integers(0, len(X), len(sizes)).astype(np.uint32)
+    side = ix.pivot_split(ids, off, pa, pb)
+    for s in range(len(sizes)):
+        for i in range(int(off[s]), int(off[s + 1])):
+            da = oracle.distance(X[ids[i]], X[pa[s]]); db = oracle.distance(X[ids[i]], X[pb[s]])
+            assert side[i] == (0 if da <= db else 1)
+    ix.close()
+
+
+def test_file_formats_roundtrip(tmp_path):
+    g = np.zeros((5, 4), np.uint32); g[0, :3] = [2, 4, 1]; g[3, :4] = [3, 0, 1, 2]
+    io.write_graph(tmp_path / "g", g)
+    np.testing.assert_array_equal(io.read_graph(tmp_path / "g"), g)
+    x = np.arange(12, dtype=np.float32).reshape(3, 4)
+    io.write_bin(tmp_path / "x.bin", x)
+    np.testing.assert_array_equal(io.read_bin(tmp_path / "x.bin", np.float32), x)

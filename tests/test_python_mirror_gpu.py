@@ -1,0 +1,142 @@
+"""The Python mirror of python/wrapper.py + python/graph_index.cpp (names, argument orders,
+quantised search + rerank) over the C-ABI, checked against compositions of oracle calls."""
+import numpy as np
+import pytest
+
+from parlayann_amd import datasets, io, quantize, wrapper
+
+pytestmark = pytest.mark.gpu
+
+
+def _overlap(a, b):
+    return np.mean([len(set(x.tolist()) & set(y.tolist())) / len(x) for x, y in zip(a, b)])
+
+
+def test_uint8_euclidian_index_end_to_end(tmp_path, oracle, capsys):
+    X = datasets.sift_like(6000, 128, seed=1234, dtype=np.uint8)
+    Q = datasets.sift_like(150, 128, seed=4321, dtype=np.uint8)
+    io.write_bin(tmp_path / "b.bin", X); io.write_bin(tmp_path / "q.bin", Q)
+    wrapper.build_vamana_index("Euclidian", "uint8", str(tmp_path / "b.bin"), str(tmp_path / "g"), 32, 64, 1.2, False, seed=4)
+    Go, _ = oracle.vamana_build(X, 32, 64, 1.2, num_passes=1, seed=4)
+    G = io.read_graph(tmp_path / "g")
+    np.testing.assert_array_equal(G[:, 0], Go[:, 0])
+    Index = wrapper.load_index("Euclidian", "uint8", str(tmp_path / "b.bin"), str(tmp_path / "g"))
+    ids, dists = Index.batch_search(Q, 10, 64, True, 1000)          # quant has no effect for 1-byte types (:86)
+    o = oracle.batch_search(X, G, queries=Q, k=10, beam=64, cut=1.35, limit=1000, degree_limit=min(32, 3000))
+    np.testing.assert_array_equal(ids, o["ids"]); np.testing.assert_array_equal(dists, o["dists"])
+    ids2, _ = Index.batch_search_from_string(str(tmp_path / "q.bin"), 10, 64, True, 1000)
+    np.testing.assert_array_equal(ids2, ids)
+    np.testing.assert_array_equal(Index.single_search(Q[3], 10, 64, False, 1000), ids[3])
+    # degree_limit = min(maxDeg, 3*visit_limit) (graph_index.cpp:198)
+    ids3, _ = Index.batch_search(Q, 10, 64, False, 5)
+    o3 = oracle.batch_search(X, G, queries=Q, k=10, beam=64, cut=1.35, limit=5, degree_limit=15)
+    np.testing.assert_array_equal(ids3, o3["ids"])
+    gt, gd = oracle.bruteforce_knn(X, Q, 100)
+    io.write_ibin(tmp_path / "gt", gt, gd)
+    rec = Index.check_recall(str(tmp_path / "q.bin"), str(tmp_path / "gt"), ids, 10)
+    assert "Recall: " in capsys.readouterr().out and abs(rec - oracle.recall(ids, gt, gd, 10)) < 1e-9
+    with pytest.raises(Exception):
+        wrapper.load_index("cosine", "uint8", "x", "y")
+
+
+def test_float_euclidian_quantised_search_and_rerank(tmp_path, oracle):
+    X = (datasets.deep_like(6000, 96, seed=1) * 2.0).astype(np.float32)
+    Q = (datasets.deep_like(120, 96, seed=2) * 2.0).astype(np.float32)
+    io.write_bin(tmp_path / "b.bin", X)
+    wrapper.build_vamana_index("Euclidian", "float", str(tmp_path / "b.bin"), str(tmp_path / "g"), 32, 64, 1.2, False)
+    G = io.read_graph(tmp_path / "g")
+    Index = wrapper.load_index("Euclidian", "float", str(tmp_path / "b.bin"), str(tmp_path / "g"))
+    assert Index.use_quantization and not Index.eparams.identity
+    ids, dists = Index.batch_search(Q, 10, 64, True, 1000)
+    # oracle composition of beam_search_rerank (beamSearch.h:390-454): search the u8 copy, exact re-score, sort
+    slope, offset = oracle.euclid_u8_params(X)
+    Xq = oracle.euclid_u8_translate(X, slope, offset); Qq = oracle.euclid_u8_translate(Q, slope, offset)
+    o = oracle.batch_search(Xq, G, queries=Qq, k=10, beam=64, cut=1.35, limit=1000, degree_limit=32, out_k=64)
+    exp = []
+    for i in range(len(Q)):
+        c = o["ids"][i, :min(o["frontier_size"][i], 1000)]
+        d = np.array([oracle.distance(Q[i], X[j]) for j in c], np.float32)
+        exp.append(c[np.lexsort((c, d))][:10])
+    exp = np.array(exp)
+    assert _overlap(ids, exp) > 0.995        # real-valued floats: ulp-level ties may reorder (DESIGN.md float order)
+    ex_d = np.array([[oracle.distance(Q[i], X[j]) for j in ids[i]] for i in range(len(Q))], np.float32)
+    np.testing.assert_allclose(dists, ex_d, rtol=2e-6, atol=1e-7)
+    # un-quantised search on the float points
+    ids_f, _ = Index.batch_search(Q, 10, 64, False, 1000)
+    of = oracle.batch_search(X, G, queries=Q, k=10, beam=64, cut=1.35, limit=1000, degree_limit=32)
+    assert _overlap(ids_f, of["ids"]) > 0.99
+
+
+def test_float_integer_valued_uses_plain_u8_copy(tmp_path, oracle):
+    X = datasets.sift_like(5000, 128, seed=1234, dtype=np.float32)
+    Q = datasets.sift_like(100, 128, seed=4321, dtype=np.float32)
+    io.write_bin(tmp_path / "b.bin", X)
+    wrapper.build_vamana_index("Euclidian", "float", str(tmp_path / "b.bin"), str(tmp_path / "g"), 32, 64, 1.2, True)
+    G = io.read_graph(tmp_path / "g")
+    Index = wrapper.load_index("Euclidian", "float", str(tmp_path / "b.bin"), str(tmp_path / "g"))
+    assert Index.eparams.identity                                   # slope 1 -> beam_search on the u8 copy (:148-152)
+    ids, dists = Index.batch_search(Q, 10, 64, True, 1000)
+    o = oracle.batch_search(X.astype(np.uint8), G, queries=Q.astype(np.uint8), k=10, beam=64, cut=1.35, limit=1000,
+                            degree_limit=32)
+    np.testing.assert_array_equal(ids, o["ids"]); np.testing.assert_array_equal(dists, o["dists"])
+    ids_f, d_f = Index.batch_search(Q, 10, 64, False, 1000)         # integer-valued floats: bit-exact as well
+    np.testing.assert_array_equal(ids_f, o["ids"]); np.testing.assert_array_equal(d_f, o["dists"])
+
+
+def test_float_mips_quantised(tmp_path, oracle):
+    X = datasets.t2i_like(6000, 200, seed=1)
+    Q = datasets.t2i_like(100, 200, seed=2)
+    io.write_bin(tmp_path / "b.bin", X)
+    wrapper.build_vamana_index("mips", "float", str(tmp_path / "b.bin"), str(tmp_path / "g"), 40, 80, 1.0, False)
+    G = io.read_graph(tmp_path / "g")
+    assert G[:, 0].max() <= 40 and G[:, 0].mean() > 5
+    Index = wrapper.load_index("mips", "float", str(tmp_path / "b.bin"), str(tmp_path / "g"))
+    ids, dists = Index.batch_search(Q, 10, 64, True, 1000)
+    Xn = oracle.normalize(X); Qn = oracle.normalize(Q)
+    mv = oracle.mips_i8_maxval(Xn, trim=True)
+    Xq = oracle.mips_i8_translate(Xn, mv); Qq = oracle.mips_i8_translate(Qn, mv)
+    o = oracle.batch_search(Xq, G, queries=Qq, k=10, beam=64, cut=1.35, limit=1000, degree_limit=40, metric="mips", out_k=64)
+    exp = []
+    for i in range(len(Q)):
+        c = o["ids"][i, :min(o["frontier_size"][i], 1000)]
+        d = np.array([oracle.distance(Qn[i], Xn[j], "mips") for j in c], np.float32)
+        exp.append(c[np.lexsort((c, d))][:10])
+    assert _overlap(ids, np.array(exp)) > 0.995
+    gt, gd = oracle.bruteforce_knn(Xn, Qn, 100, metric="mips")
+    assert oracle.recall(ids, gt, gd, 10) > 0.8
+
+
+def test_hcnng_wrapper(tmp_path, oracle):
+    X = datasets.sift_like(6000, 128, seed=1234, dtype=np.uint8)
+    Q = datasets.sift_like(100, 128, seed=4321, dtype=np.uint8)
+    io.write_bin(tmp_path / "b.bin", X)
+    wrapper.build_hcnng_index("Euclidian", "uint8", str(tmp_path / "b.bin"), str(tmp_path / "h"), 3, 12, 300)
+    G = io.read_graph(tmp_path / "h")
+    assert G.shape[1] - 1 == 36
+    Index = wrapper.load_index("Euclidian", "uint8", str(tmp_path / "b.bin"), str(tmp_path / "h"))
+    ids, _ = Index.batch_search(Q, 10, 64, False, 1000)
+    gt, gd = oracle.bruteforce_knn(X, Q, 100)
+    assert oracle.recall(ids, gt, gd, 10) > 0.9
+    o = oracle.batch_search(X, G, queries=Q, k=10, beam=64, cut=1.35, limit=1000, degree_limit=36)
+    np.testing.assert_array_equal(ids, o["ids"])
+
+
+def test_rerank_no_resort_keeps_order(oracle):
+    from parlayann_amd import DeviceIndex
+    X = datasets.sift_like(3000, 64, seed=1, dtype=np.float32)
+    Q = datasets.sift_like(20, 64, seed=2, dtype=np.float32)
+    ix = DeviceIndex(X, max_degree=8)
+    rng = np.random.default_rng(0)
+    cand = rng.integers(0, len(X), (len(Q), 50)).astype(np.uint32)
+    cnt = rng.integers(5, 51, len(Q)).astype(np.uint32)
+    ids, d = ix.rerank(Q, cand, cnt, 5, resort=False)                # beamSearch.h:447-452
+    np.testing.assert_array_equal(ids, cand[:, :5])
+    np.testing.assert_array_equal(d, np.array([[oracle.distance(Q[i], X[j]) for j in cand[i, :5]] for i in range(len(Q))], np.float32))
+    ids, d = ix.rerank(Q, cand, cnt, 5, resort=True)
+    for i in range(len(Q)):
+        c = cand[i, :cnt[i]]
+        dd = np.array([oracle.distance(Q[i], X[j]) for j in c], np.float32)
+        # duplicates among random candidates stay duplicated, as std::sort would leave them
+        order = np.lexsort((c, dd))[:5]
+        np.testing.assert_array_equal(ids[i], c[order]); np.testing.assert_array_equal(d[i], dd[order])
+    ix.close()
