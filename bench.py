@@ -58,10 +58,6 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)   # RCCL; used only for barriers + max-over-ranks
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
     # ---- synthetic SIFT-1M-shaped data: integer-valued in [0,255] (see datasets.sift_like) ----
     t0 = time.time()
     Xf = datasets.sift_like(args.n, args.d, seed=1234, dtype=np.float32)      # the reference's float points
@@ -97,22 +93,22 @@ def main():
         check(lib.pann_batch_search_dev(ix.handle, d_q.data_ptr(), None, args.nq, args.d * 2, d_starts.data_ptr(), 1,
                                         C.byref(qp), C.byref(out), C.c_void_p(stream.cuda_stream)))
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
-
-    # ---- timed region: exactly --steps steps; per-launch HIP events on the launch stream ----
+    # ---- timed region: exactly --steps steps (barrier + synchronize on both sides, MAX over ranks:
+    # parlayann_amd.distributed.timed_steps); per-launch HIP events on the launch stream ----
+    from parlayann_amd import distributed as D
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    barrier(); torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for a, b in evs:
+    it = iter(evs)
+    warm = [args.warmup]
+
+    def timed_step():
+        if warm[0] > 0:
+            warm[0] -= 1
+            step()
+            return
+        a, b = next(it)
         a.record(stream); step(); b.record(stream)
-    torch.cuda.synchronize(dev); barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    elapsed = D.timed_steps(timed_step, args.steps, args.warmup, sync=lambda: torch.cuda.synchronize(dev), device=dev)
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     ms_per_step = elapsed * 1e3 / args.steps
     qps = args.nq * world / (ms_per_step / 1e3)

@@ -30,6 +30,11 @@ def _metric_code(metric):
     raise ValueError(f"unknown metric {metric!r}")
 
 
+def _row_stride(a):
+    """row stride of a C-contiguous 2-D array (numpy may report anything for a length-1 axis)"""
+    return a.shape[1] * a.itemsize
+
+
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
@@ -56,7 +61,7 @@ class DeviceIndex:
         self.n, self.d, self.max_degree = n, d, int(max_degree)
         self.dtype, self.metric = points.dtype, _metric_code(metric)
         h = C.c_void_p()
-        check(lib.pann_index_create(C.byref(h), _ptr(points), n, d, _DT[points.dtype], points.strides[0],
+        check(lib.pann_index_create(C.byref(h), _ptr(points), n, d, _DT[points.dtype], _row_stride(points),
                                     self.metric, _ptr(graph), self.max_degree, device))
         self._h, self._lib = h, lib
 
@@ -118,7 +123,7 @@ class DeviceIndex:
             q = np.ascontiguousarray(queries)
             if q.dtype != self.dtype or q.ndim != 2 or q.shape[1] != self.d:
                 raise ValueError("queries must be nq x d of the index dtype")
-            stride = q.strides[0]
+            stride = _row_stride(q)
         else:
             qid = np.ascontiguousarray(query_ids, dtype=np.uint32)
         check(self._lib.pann_batch_search(self._h, _ptr(q), _ptr(qid), nq, stride, _ptr(starts), len(starts),
@@ -161,7 +166,7 @@ class DeviceIndex:
     def query_distances(self, queries, ids):
         q = np.ascontiguousarray(queries); ids = np.ascontiguousarray(ids, dtype=np.uint32)
         out = np.empty((len(q), len(ids)), np.float32)
-        check(self._lib.pann_query_distances(self._h, _ptr(q), len(q), q.strides[0], _ptr(ids), len(ids), _ptr(out)))
+        check(self._lib.pann_query_distances(self._h, _ptr(q), len(q), _row_stride(q), _ptr(ids), len(ids), _ptr(out)))
         return out
 
     def leaf_knn_batch(self, ids, leaf_offsets, m):
@@ -179,7 +184,7 @@ class DeviceIndex:
         """data_tools/compute_groundtruth.cpp:22-59."""
         q = np.ascontiguousarray(queries)
         oi = np.empty((len(q), k), np.uint32); od = np.empty((len(q), k), np.float32)
-        check(self._lib.pann_bruteforce_knn(self._h, _ptr(q), len(q), q.strides[0], k, _ptr(oi), _ptr(od)))
+        check(self._lib.pann_bruteforce_knn(self._h, _ptr(q), len(q), _row_stride(q), k, _ptr(oi), _ptr(od)))
         return oi, od
 
     def pivot_split(self, ids, seg_offsets, pivot_a, pivot_b):
@@ -197,6 +202,6 @@ class DeviceIndex:
         cand = np.ascontiguousarray(cand_ids, dtype=np.uint32)
         cnt = None if cand_counts is None else np.ascontiguousarray(cand_counts, dtype=np.uint32)
         oi = np.empty((len(q), k), np.uint32); od = np.empty((len(q), k), np.float32)
-        check(self._lib.pann_rerank(self._h, _ptr(q), len(q), q.strides[0], _ptr(cand), cand.shape[1], _ptr(cnt), k,
+        check(self._lib.pann_rerank(self._h, _ptr(q), len(q), _row_stride(q), _ptr(cand), cand.shape[1], _ptr(cnt), k,
                                     1 if resort else 0, _ptr(oi), _ptr(od)))
         return oi, od
