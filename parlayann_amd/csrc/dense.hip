@@ -183,6 +183,141 @@ __global__ void __launch_bounds__(256) dense_topk_kernel(DenseArgs A) {
   }
 }
 
+// ---- fp16 variant on the matrix cores (north_star: MFMA only for the dense fp16 contraction) ----
+// Same tiling as dense_topk_kernel.  Each wave owns 16 A rows and computes the 16 x 64 block of dot
+// products against the B tile with v_mfma_f32_16x16x32_f16 (A and B fragments are both "row with k
+// contiguous", i.e. plain ds_read_b128 from the padded LDS tiles); distances are
+//   L2 : |a|^2 + |b|^2 - 2 a.b      MIPS : -a.b
+// with the row norms summed in f32 while the tiles are staged.  On integer-valued data every
+// product and partial sum is exact, so the result is bit-identical to the VALU path; on real-valued
+// data the norm form differs from sum((a-b)^2) by cancellation error (DESIGN.md "float order").
+typedef _Float16 mf_half8 __attribute__((ext_vector_type(8)));
+typedef float mf_float4 __attribute__((ext_vector_type(4)));
+
+template <int METRIC>
+__global__ void __launch_bounds__(256) dense_topk_mfma_f16_kernel(DenseArgs A) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  uint8_t* At = smem;                                   // [64][DT_BSTRIDE]
+  uint8_t* Bt = At + DT_A * DT_BSTRIDE;                 // [64][DT_BSTRIDE]
+  uint32_t* Bid = reinterpret_cast<uint32_t*>(Bt + DT_B * DT_BSTRIDE);
+  uint32_t* Aid = Bid + DT_B;
+  float* An = reinterpret_cast<float*>(Aid + DT_A);     // [64] |a|^2
+  float* Bn = An + DT_A;                                // [64] |b|^2
+  uint64_t* lists = reinterpret_cast<uint64_t*>(Bn + DT_B);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t seg = A.tile_seg ? A.tile_seg[blockIdx.x] : 0u;
+  const uint64_t a_hi = A.a_off ? A.a_off[seg + 1] : A.na;
+  const uint64_t b_lo = A.b_off ? A.b_off[seg] : 0ull, b_hi = A.b_off ? A.b_off[seg + 1] : A.nb;
+  const uint64_t a0 = A.tile_a0 ? (uint64_t)A.tile_a0[blockIdx.x] : (uint64_t)blockIdx.x * DT_A;
+  const uint32_t na_tile = (uint32_t)min((uint64_t)DT_A, a_hi - a0);
+  const uint64_t nb_seg = b_hi - b_lo;
+  const uint64_t per = ((nb_seg + A.nsplit - 1) / A.nsplit + DT_B - 1) / DT_B * DT_B;
+  const uint64_t bs = b_lo + min(nb_seg, (uint64_t)blockIdx.y * per);
+  const uint64_t be = b_lo + min(nb_seg, (uint64_t)(blockIdx.y + 1) * per);
+
+  for (uint32_t i = tid; i < DT_A * A.mcap; i += 256) lists[i] = KEY_INF;
+  if (tid < DT_A) { Aid[tid] = (tid < (int)na_tile && A.a_ids) ? A.a_ids[a0 + tid] : SENTINEL; An[tid] = 0.f; }
+  __syncthreads();
+  const uint32_t nseg = (A.pstride + DT_SEG - 1) / DT_SEG;
+
+  // stage one 256-byte segment of 64 rows (16 threads x 16 B per row) and add its squared norm
+  auto stage_rows = [&](uint8_t* dst, float* norms, uint32_t sg, auto rowptr, uint32_t valid, uint32_t nrows) {
+    const int r0 = tid >> 4, c = tid & 15;
+    for (int r = r0; r < 64; r += 16) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      const uint32_t off = sg * DT_SEG + c * 16;
+      if (r < (int)nrows) {
+        const uint8_t* rp = rowptr(r);
+        if ((reinterpret_cast<uintptr_t>(rp) & 15) == 0) v = load16_guarded(rp, off, valid);
+        else {
+          uint8_t tmp[16];
+#pragma unroll
+          for (int i = 0; i < 16; i++) tmp[i] = (off + i < valid) ? rp[off + i] : (uint8_t)0;
+          __builtin_memcpy(&v, tmp, 16);
+        }
+      }
+      *reinterpret_cast<uint4*>(dst + (size_t)r * DT_BSTRIDE + c * 16) = v;
+      mf_half8 h; __builtin_memcpy(&h, &v, 16);
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; i++) { const float f = (float)h[i]; ss = fmaf(f, f, ss); }
+      ss = group_sum<16>(ss);                       // the 16 threads of a row are 16 consecutive lanes
+      if (c == 0) norms[r] += ss;
+    }
+  };
+  auto a_rowptr = [&](int r) -> const uint8_t* {
+    return A.a_ids ? A.points + (uint64_t)A.a_ids[a0 + r] * A.pstride : A.a_ext + (a0 + r) * A.a_stride;
+  };
+  const uint32_t a_valid = A.a_ids ? A.pstride : A.dbytes;
+  if (nseg == 1) stage_rows(At, An, 0, a_rowptr, a_valid, na_tile);
+
+  for (uint64_t bt = bs; bt < be; bt += DT_B) {
+    const uint32_t nb_tile = (uint32_t)min((uint64_t)DT_B, be - bt);
+    auto b_rowptr = [&](int r) -> const uint8_t* {
+      const uint64_t id = A.b_ids ? (uint64_t)A.b_ids[bt + r] : (bt + r);
+      return A.points + id * A.pstride;
+    };
+    mf_float4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[t] = mf_float4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    if (tid < DT_B) { Bid[tid] = tid < (int)nb_tile ? (A.b_ids ? A.b_ids[bt + tid] : (uint32_t)(bt + tid)) : SENTINEL; Bn[tid] = 0.f; }
+    if (nseg > 1 && tid < DT_A) An[tid] = 0.f;
+    __syncthreads();
+    for (uint32_t sg = 0; sg < nseg; sg++) {
+      if (sg > 0) __syncthreads();
+      stage_rows(Bt, Bn, sg, b_rowptr, A.pstride, nb_tile);
+      if (nseg > 1) stage_rows(At, An, sg, a_rowptr, a_valid, na_tile);
+      __syncthreads();
+      const uint32_t ksteps = min((uint32_t)DT_SEG, A.pstride - sg * DT_SEG) / 64;   // 32 halves per MFMA
+      for (uint32_t ks = 0; ks < ksteps; ks++) {
+        const uint32_t koff = ks * 64 + (lane >> 4) * 16;                              // k = 8*(lane>>4) + j
+        const mf_half8 af = *reinterpret_cast<const mf_half8*>(At + (size_t)(wave * DT_AW + (lane & 15)) * DT_BSTRIDE + koff);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const mf_half8 bf = *reinterpret_cast<const mf_half8*>(Bt + (size_t)(t * 16 + (lane & 15)) * DT_BSTRIDE + koff);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    // ---- epilogue: C[row = 4*(lane>>4) + r][col = lane&15] of tile t -> distance, top-m update ----
+    const int q = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const uint32_t ar = wave * DT_AW + q * 4 + r;          // this lane's A row for register r
+      const float an = An[ar];
+      uint64_t* mylist = lists + (size_t)ar * A.mcap;
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const uint32_t bc = t * 16 + (lane & 15);
+        const uint32_t bid = Bid[bc];
+        float dist;
+        if constexpr (METRIC == PANN_L2) dist = (an + Bn[bc]) - 2.0f * acc[t][r];
+        else dist = -acc[t][r];
+        const uint64_t key = make_key(dist, bid);
+        bool ok = (bc < nb_tile) && (ar < na_tile);
+        if (A.exclude_same_id) ok = ok && (bid != Aid[ar]);
+        const uint64_t tau = mylist[A.m - 1];
+        uint64_t mask = __ballot(ok && key < tau);
+        while (mask) {                                        // rare after the first tiles
+          const int L = __ffsll((unsigned long long)mask) - 1;
+          const uint32_t klo = __builtin_amdgcn_readlane((uint32_t)key, L);
+          const uint32_t khi = __builtin_amdgcn_readlane((uint32_t)(key >> 32), L);
+          const uint64_t x = ((uint64_t)khi << 32) | klo;
+          mask &= mask - 1;
+          uint64_t* list = lists + (size_t)(wave * DT_AW + (L >> 4) * 4 + r) * A.mcap;
+          if (x < list[A.m - 1]) list_insert(list, A.mcap, x, lane);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < na_tile * A.m; i += 256) {
+    const uint32_t ar = i / A.m, j = i % A.m;
+    A.partial[((a0 + ar) * A.nsplit + blockIdx.y) * A.m + j] = lists[(size_t)ar * A.mcap + j];
+  }
+}
+
 // merge the nsplit partial lists of each A row (one wave per row) and write ids / dists
 __global__ void __launch_bounds__(64) dense_merge_kernel(const uint64_t* partial, uint64_t na, uint32_t nsplit,
                                                          uint32_t m, uint32_t mcap, uint32_t* out_ids, float* out_dists) {
@@ -250,8 +385,17 @@ int dense_topk_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, const u
   else if (ix.dtype == PANN_I8) CALL_DENSE(PANN_I8, PANN_MIPS);
   else if (ix.dtype == PANN_F32 && ix.metric == PANN_L2) CALL_DENSE(PANN_F32, PANN_L2);
   else if (ix.dtype == PANN_F32) CALL_DENSE(PANN_F32, PANN_MIPS);
-  else if (ix.dtype == PANN_F16 && ix.metric == PANN_L2) CALL_DENSE(PANN_F16, PANN_L2);
-  else CALL_DENSE(PANN_F16, PANN_MIPS);
+  else {
+    const size_t lds2 = (size_t)(DT_A + DT_B) * DT_BSTRIDE + (DT_A + DT_B) * 8 + (size_t)DT_A * mcap * 8;
+#define CALL_MFMA(MT)                                                                                   \
+  do {                                                                                                   \
+    auto kern = dense_topk_mfma_f16_kernel<MT>;                                                          \
+    if (lds2 > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds2, st, A);                                              \
+  } while (0)
+    if (ix.metric == PANN_L2) CALL_MFMA(PANN_L2); else CALL_MFMA(PANN_MIPS);
+#undef CALL_MFMA
+  }
 #undef CALL_DENSE
   PANN_HIP(hipGetLastError());
   hipLaunchKernelGGL(dense_merge_kernel, dim3((uint32_t)na), dim3(64), (size_t)mcap * 8, st,

@@ -14,7 +14,8 @@ def _mk(n, d, dtype, seed=1234):
 
 
 @pytest.mark.parametrize("dtype,metric,d", [(np.uint8, "l2", 128), (np.float16, "l2", 128), (np.float32, "l2", 96),
-                                            (np.int8, "mips", 200), (np.float32, "mips", 200), (np.uint8, "l2", 20)])
+                                            (np.int8, "mips", 200), (np.float32, "mips", 200), (np.uint8, "l2", 20),
+                                            (np.float16, "l2", 96), (np.float16, "mips", 200), (np.float16, "l2", 40)])
 def test_leaf_knn(oracle, dtype, metric, d):
     X = _mk(5000, d, dtype)
     ix = DeviceIndex(X, max_degree=8, metric=metric)
@@ -31,7 +32,8 @@ def test_leaf_knn(oracle, dtype, metric, d):
 
 
 @pytest.mark.parametrize("dtype,metric,d,k", [(np.uint8, "l2", 128, 100), (np.float16, "l2", 128, 10),
-                                              (np.int8, "mips", 200, 100), (np.float32, "l2", 96, 37)])
+                                              (np.int8, "mips", 200, 100), (np.float32, "l2", 96, 37),
+                                              (np.float16, "mips", 128, 100), (np.float16, "l2", 200, 64)])
 def test_bruteforce_knn(oracle, dtype, metric, d, k):
     X = _mk(20000, d, dtype)
     Q = _mk(130, d, dtype, seed=4321)

@@ -140,3 +140,29 @@ def test_rerank_no_resort_keeps_order(oracle):
         order = np.lexsort((c, dd))[:5]
         np.testing.assert_array_equal(ids[i], c[order]); np.testing.assert_array_equal(d[i], dd[order])
     ix.close()
+
+
+def test_search_and_parse_sweep(oracle):
+    from parlayann_amd import DeviceIndex, sweep
+    X = datasets.sift_like(8000, 64, seed=1234, dtype=np.uint8)
+    Q = datasets.sift_like(200, 64, seed=4321, dtype=np.uint8)
+    G, _ = oracle.vamana_build(X, 32, 64, 1.2, seed=2)
+    ix = DeviceIndex(X, G)
+    gt, gd = ix.bruteforce_knn(Q, 100)
+    results, (best, buckets) = sweep.search_and_parse(ix, Q, gt, gd, 10)
+    assert len(results) == 43 + 20 + 1
+    by_beam = {r["beamQ"]: r for r in results[:43]}
+    # every sweep point equals the oracle at the same QueryParams (spot checks incl. beam 1000: HBM filter)
+    for beam in (10, 38, 300, 1000):
+        o = oracle.batch_search(X, G, queries=Q, k=10, beam=beam, cut=1.35)
+        assert abs(by_beam[beam]["recall"] - oracle.recall(o["ids"], gt, gd, 10)) < 1e-9
+        assert by_beam[beam]["avg_cmps"] == int(o["dist_cmps"].astype(np.uint64).sum() // len(Q))
+    lim = results[43 + 5]                                         # limit 15: beam max(15,10), degree_limit min(32,75)
+    o = oracle.batch_search(X, G, queries=Q, k=10, beam=15, cut=1.35, limit=15, degree_limit=32)
+    assert abs(lim["recall"] - oracle.recall(o["ids"], gt, gd, 10)) < 1e-9
+    best_acc = results[-1]
+    o = oracle.batch_search(X, G, queries=Q, k=100, beam=1000, cut=10.0, out_k=10)
+    assert abs(best_acc["recall"] - oracle.recall(o["ids"], gt, gd, 10)) < 1e-9
+    assert buckets == sorted(buckets) and all(b <= r["recall"] for b, r in zip(buckets, best))
+    assert by_beam[1000]["recall"] >= by_beam[10]["recall"]
+    ix.close()
