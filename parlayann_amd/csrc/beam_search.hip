@@ -20,9 +20,36 @@
 //    that re-enters the frontier after having been visited gets its flag back.  That can only
 //    happen while the frontier is not full (cut-prune :190-195 dropped it); such entries are kept
 //    in a small per-query "dropped" list and candidates are checked against it.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
 #include "pann_device.h"
 
 namespace pann {
+
+// Diagnostic build only (make STAMPS=1 -> lib/libpann_stamps.so): s_memtime at the phase boundaries
+// of an iteration, summed per query into a buffer nothing else reads (guide section 7, In-kernel
+// stamps).  In the shipped library PANN_STAMP() expands to nothing.
+#ifndef PANN_GU
+#define PANN_GU 4   /* candidate groups in flight per lane in the main gather */
+#endif
+#ifndef PANN_MINWAVES
+#define PANN_MINWAVES 1
+#endif
+#ifdef PANN_STAMPS
+#define PANN_STAMP(slot)                                                                        \
+  do {                                                                                          \
+    unsigned long long t_;                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    stamp_sum[slot] += t_ - stamp_prev;                                                         \
+    stamp_prev = t_;                                                                            \
+  } while (0)
+#else
+#define PANN_STAMP(slot) do { } while (0)
+#endif
 
 struct BSParams {
   const uint8_t* points; uint32_t pstride; uint32_t dbytes; uint32_t nch;
@@ -40,6 +67,7 @@ struct BSParams {
   uint32_t* work_counter;  // persistent variant: next query to take
   uint32_t* status;        // [0] |= 1 on visited-list overflow, |= 2 on dropped-list overflow
   pann_search_out out;
+  unsigned long long* stamps;   // diagnostic build: [nq][8] cycle sums
 };
 
 template <bool HASH_LDS>
@@ -121,8 +149,18 @@ __device__ __forceinline__ uint32_t gather_distances(const BSParams& P, const QR
   return c;
 }
 
-template <int DT, int METRIC, int LPC, bool NCH1, bool HASH_LDS>
-__global__ void __launch_bounds__(PANN_WAVE) beam_search_kernel(BSParams P) {
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
+  const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, l);
+  const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), l);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// B64: beam <= 64 (and <= 64 start points): the frontier lives in REGISTERS, lane e <-> entry e
+// (key + visited flag); the head scan is one ballot, the cutoff one readlane, and a merge with
+// <= 64 candidates is a loop of readlane/ballot steps with no LDS round trip per step.  Larger
+// merges (only while the frontier is still filling) spill to the LDS arrays and take the generic path.
+template <int DT, int METRIC, int LPC, bool NCH1, bool HASH_LDS, bool B64>
+__global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES) beam_search_kernel(BSParams P) {
   const int lane = threadIdx.x;
   extern __shared__ __align__(16) uint8_t smem[];
   // ---- LDS carve (all regions 16 B aligned): 6.4 KB at beam 64 / degree 64 -> 24 queries per CU ----
@@ -160,11 +198,17 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_kernel(BSParams P) {
     hsync<HASH_LDS>();
 
     uint32_t f = 0;        // frontier size
+    uint64_t fkey = KEY_INF;   // B64: this lane's frontier entry
+    uint32_t fflag = 0;        // B64: its visited flag (0 / 1 / 2)
     uint32_t c = 0;        // accumulated candidates
     uint32_t nvis = 0;     // num_visited
     uint32_t dcmps = P.nstarts;  // dist_cmps == full_dist_cmps (:83-84)
     uint32_t degsum = 0;
     uint32_t ndrop = 0;    // entries in the dropped list
+#ifdef PANN_STAMPS
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
     uint64_t* DL = P.dropped + (size_t)qi * P.dcap;
 
     // ---- start points (:66-70): distance for each, filter insert in order, then "merge" into
@@ -189,18 +233,30 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_kernel(BSParams P) {
         // ---- next vertex: first unvisited frontier entry (:107-109) ----
         int cur_idx = -1;
         uint32_t unv_total = 0;
-        for (uint32_t e0 = 0; e0 < f; e0 += PANN_WAVE) {
-          const uint32_t e = e0 + lane;
-          const uint64_t um = __ballot(e < f && Fv[e] == 0);
-          if (cur_idx < 0 && um) cur_idx = (int)e0 + __ffsll((unsigned long long)um) - 1;
-          unv_total += __popcll(um);
+        uint64_t cur_key;
+        if constexpr (B64) {
+          const uint64_t um = __ballot(lane < (int)f && fflag == 0);
+          unv_total = __popcll(um);
+          if (um) cur_idx = __ffsll((unsigned long long)um) - 1;
+          if (cur_idx < 0 || nvis >= P.limit) break;
+          PANN_STAMP(0);   // head scan
+          cur_key = readlane64(fkey, cur_idx);
+          if (lane == cur_idx) fflag = 1;
+        } else {
+          for (uint32_t e0 = 0; e0 < f; e0 += PANN_WAVE) {
+            const uint32_t e = e0 + lane;
+            const uint64_t um = __ballot(e < f && Fv[e] == 0);
+            if (cur_idx < 0 && um) cur_idx = (int)e0 + __ffsll((unsigned long long)um) - 1;
+            unv_total += __popcll(um);
+          }
+          if (cur_idx < 0 || nvis >= P.limit) break;
+          PANN_STAMP(0);   // head scan
+          cur_key = F[cur_idx];
         }
-        if (cur_idx < 0 || nvis >= P.limit) break;
-        const uint64_t cur_key = F[cur_idx];
         const uint32_t cur = key_id(cur_key);
         // ---- visited.insert(current) (:112-114) ----
         if (lane == 0) {
-          Fv[cur_idx] = 1;
+          if constexpr (!B64) Fv[cur_idx] = 1;
           if (P.out.visited_cap) {
             if (nvis < P.out.visited_cap) {
               if (P.out.visited_ids) P.out.visited_ids[(size_t)qi * P.out.visited_cap + nvis] = cur;
@@ -213,7 +269,8 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_kernel(BSParams P) {
         nvis++;
         const bool more_unvisited = unv_total > 1;         // offset + 1 < remain (:165)
         const bool full = (f == beam);                      // :115
-        const uint32_t cutoff_ord = full ? (uint32_t)(F[f - 1] >> 32) : BIG_ORD;  // :150-152
+        uint32_t cutoff_ord = BIG_ORD;                      // :150-152
+        if (full) cutoff_ord = B64 ? (uint32_t)(readlane64(fkey, (int)f - 1) >> 32) : (uint32_t)(F[f - 1] >> 32);
 
         // ---- adjacency row: lane i <- slot i; degree = number of non-sentinel slots ----
         const uint32_t* row = P.graph + (size_t)cur * P.gstride;
@@ -223,6 +280,7 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_kernel(BSParams P) {
           if (i < P.gstride) a = row[i];
           const bool act = (a != SENTINEL) && (i < P.degree_limit);   // min(size, degree_limit) (:130)
           const uint64_t am = __ballot(act);
+          PANN_STAMP(1);   // adjacency row arrived
           if (am == 0ull) break;
           degsum += __popcll(am);
           const bool seen = filter_update<HASH_LDS>(H, hmask, act, a, lane);
@@ -232,8 +290,10 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_kernel(BSParams P) {
           if (keep) PANN_PL[lanes_below(km, lane)] = a;
           dcmps += m;                                                 // :137,155
           __syncthreads();
-          if (m) c = gather_distances<DT, METRIC, LPC, NCH1, 4>(P, qreg, qlds, PANN_PL, m, cutoff_ord, C, c, lane);
+          PANN_STAMP(2);   // filter + compaction
+          if (m) c = gather_distances<DT, METRIC, LPC, NCH1, PANN_GU>(P, qreg, qlds, PANN_PL, m, cutoff_ord, C, c, lane);
           __syncthreads();
+          PANN_STAMP(3);   // gather + distances
         }
         // ---- skip the merge while too few candidates (:162-168) ----
         __syncthreads();
@@ -241,101 +301,173 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_kernel(BSParams P) {
         do_merge = !skip;
       }
       if (do_merge) {
-        // ================= merge: sort+unique(C), set_union with F, trim (:173-185) =========
-        // A1: kill duplicates (same id <=> same key) and entries already in F; remember rank in F
-        for (uint32_t j0 = 0; j0 < c; j0 += PANN_WAVE) {
-          const uint32_t j = j0 + lane;
-          uint64_t key = KEY_INF;
-          uint32_t p = 0;
-          if (j < c) {
-            key = C[j];
-            bool dead = false;
-            for (uint32_t i = 0; i < j; i++) dead |= (C[i] == key);
-            p = lower_bound_lds(F, f, key);
-            dead |= (p < f && F[p] == key);
-            if (dead) key = KEY_INF;
-          }
-          __syncthreads();       // all reads of C[0..j) by this chunk are done
-          if (j < c) { C[j] = key; CP[j] = (uint16_t)p; }
-          // later chunks compare against earlier ORIGINAL keys; a killed earlier key was itself a
-          // duplicate of a still earlier live one (or of F), so the verdict is unchanged.
-          __syncthreads();
-        }
-        // A2: rank among live candidates -> direct placement into NF
-        uint32_t nvalid = 0;
-        for (uint32_t j0 = 0; j0 < c; j0 += PANN_WAVE) {
-          const uint32_t j = j0 + lane;
-          const uint64_t key = j < c ? C[j] : KEY_INF;
-          nvalid += __popcll(__ballot(key != KEY_INF));
-          if (key != KEY_INF) {
-            uint32_t r = 0;
-            for (uint32_t i = 0; i < c; i++) r += (C[i] < key) ? 1u : 0u;   // dead entries are KEY_INF
-            const uint32_t pos = r + CP[j];
-            if (pos < beam) {
+        bool generic = true;
+        if constexpr (B64) {
+          if (c <= (uint32_t)PANN_WAVE) {
+            generic = false;
+            // ============ register merge: sort+unique(C), set_union with F, trim (:173-185) ============
+            const uint64_t ckey = (lane < (int)c) ? C[lane] : KEY_INF;
+            const bool fl = lane < (int)f;
+            uint32_t myp = 0, rank_c = 0, below_f = 0;
+            uint64_t live_mask = 0;
+            for (uint32_t i = 0; i < c; i++) {
+              const uint64_t kk = readlane64(ckey, (int)i);
+              const uint64_t ltm = __ballot(fl && fkey < kk);                 // frontier entries below candidate i
+              const uint64_t eqm = __ballot(fl && fkey == kk);                // already in the frontier (set_union)
+              const uint64_t dupm = __ballot(lane < (int)i && ckey == kk);    // duplicate of an earlier candidate (std::unique)
+              if (eqm == 0ull && dupm == 0ull) {
+                live_mask |= 1ull << i;
+                if (lane == (int)i) myp = __popcll(ltm);
+                rank_c += (kk < ckey) ? 1u : 0u;
+                below_f += (kk < fkey) ? 1u : 0u;
+              }
+            }
+            const uint32_t nvalid = __popcll(live_mask);
+            const bool clive = (lane < (int)c) && ((live_mask >> lane) & 1ull);
+            const uint32_t cpos = rank_c + myp, fpos = (uint32_t)lane + below_f;
+            if (clive && cpos < beam) {
               uint32_t flag = 0u;   // re-entry of an already visited vertex? (only while not full)
               for (uint32_t t = 0; t < ndrop; t++)
-                flag |= (__hip_atomic_load(DL + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key) ? 2u : 0u;
-              NF[pos] = key; NFv[pos] = (uint8_t)flag;
+                flag |= (__hip_atomic_load(DL + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ckey) ? 2u : 0u;
+              F[cpos] = ckey; Fv[cpos] = (uint8_t)flag;
+            }
+            if (fl && fpos < beam) { F[fpos] = fkey; Fv[fpos] = (uint8_t)fflag; }
+            __syncthreads();
+            const uint32_t f_old = f;
+            uint32_t f_new = min(f_old + nvalid, beam);   // :185
+            const uint64_t nkey = (lane < (int)f_new) ? F[lane] : KEY_INF;
+            const uint32_t nflag = (lane < (int)f_new) ? (uint32_t)Fv[lane] : 0u;
+            if (!first && P.cut_enabled && f_new > P.k) {  // cut-prune (:190-195)
+              const float dk = key_dist(readlane64(nkey, (int)P.k));
+              const float thr = (float)(P.cut * (double)dk);
+              const uint64_t thr_key = (uint64_t)f2ord(thr) << 32;
+              const uint32_t ub = __popcll(__ballot(lane < (int)f_new && nkey <= thr_key));
+              f_new = max(ub, f_old);
+            }
+            if (f_new == beam) {
+              ndrop = 0;
+            } else if (P.cut_enabled && !first) {
+              const bool lost = fl && fflag == 1u && fpos >= f_new;
+              const uint64_t lm = __ballot(lost);
+              if (lost) {
+                const uint32_t at = ndrop + lanes_below(lm, lane);
+                if (at < P.dcap) DL[at] = fkey; else atomicOr(P.status, 2u);
+              }
+              ndrop = min(ndrop + (uint32_t)__popcll(lm), P.dcap);
+              if (lm) __builtin_amdgcn_s_waitcnt(0);
+            }
+            fkey = nkey; fflag = nflag;
+            f = f_new;
+            c = 0;
+            __syncthreads();
+          } else {
+            if (lane < (int)f) { F[lane] = fkey; Fv[lane] = (uint8_t)fflag; }   // spill for the generic path
+            __syncthreads();
+          }
+        }
+        if (generic) {
+          // ================= merge: sort+unique(C), set_union with F, trim (:173-185) =========
+          // A1: kill duplicates (same id <=> same key) and entries already in F; remember rank in F
+          for (uint32_t j0 = 0; j0 < c; j0 += PANN_WAVE) {
+            const uint32_t j = j0 + lane;
+            uint64_t key = KEY_INF;
+            uint32_t p = 0;
+            if (j < c) {
+              key = C[j];
+              bool dead = false;
+              for (uint32_t i = 0; i < j; i++) dead |= (C[i] == key);
+              p = lower_bound_lds(F, f, key);
+              dead |= (p < f && F[p] == key);
+              if (dead) key = KEY_INF;
+            }
+            __syncthreads();       // all reads of C[0..j) by this chunk are done
+            if (j < c) { C[j] = key; CP[j] = (uint16_t)p; }
+            // later chunks compare against earlier ORIGINAL keys; a killed earlier key was itself a
+            // duplicate of a still earlier live one (or of F), so the verdict is unchanged.
+            __syncthreads();
+          }
+          // A2: rank among live candidates -> direct placement into NF
+          uint32_t nvalid = 0;
+          for (uint32_t j0 = 0; j0 < c; j0 += PANN_WAVE) {
+            const uint32_t j = j0 + lane;
+            const uint64_t key = j < c ? C[j] : KEY_INF;
+            nvalid += __popcll(__ballot(key != KEY_INF));
+            if (key != KEY_INF) {
+              uint32_t r = 0;
+              for (uint32_t i = 0; i < c; i++) r += (C[i] < key) ? 1u : 0u;   // dead entries are KEY_INF
+              const uint32_t pos = r + CP[j];
+              if (pos < beam) {
+                uint32_t flag = 0u;   // re-entry of an already visited vertex? (only while not full)
+                for (uint32_t t = 0; t < ndrop; t++)
+                  flag |= (__hip_atomic_load(DL + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key) ? 2u : 0u;
+                NF[pos] = key; NFv[pos] = (uint8_t)flag;
+              }
             }
           }
-        }
-        // B: old frontier entries move right by the number of live candidates below them
-        for (uint32_t e0 = 0; e0 < f; e0 += PANN_WAVE) {
-          const uint32_t e = e0 + lane;
-          if (e < f) {
-            const uint64_t key = F[e];
-            uint32_t below = 0;
-            for (uint32_t i = 0; i < c; i++) below += (C[i] < key) ? 1u : 0u;
-            const uint32_t pos = e + below;
-            if (pos < beam) { NF[pos] = key; NFv[pos] = Fv[e]; }
-          }
-        }
-        __syncthreads();
-        const uint32_t f_old = f;
-        uint32_t f_new = min(f_old + nvalid, beam);   // :185
-        // ---- cut-prune (:190-195) ----
-        if (!first && P.cut_enabled && f_new > P.k) {
-          const float dk = key_dist(NF[P.k]);
-          const float thr = (float)(P.cut * (double)dk);
-          const uint64_t thr_key = (uint64_t)f2ord(thr) << 32;   // pair{0, thr}: kept iff key <= thr_key
-          uint32_t ub = 0;
-          for (uint32_t e0 = 0; e0 < f_new; e0 += PANN_WAVE) {
+          // B: old frontier entries move right by the number of live candidates below them
+          for (uint32_t e0 = 0; e0 < f; e0 += PANN_WAVE) {
             const uint32_t e = e0 + lane;
-            ub += __popcll(__ballot(e < f_new && NF[e] <= thr_key));
-          }
-          f_new = max(ub, f_old);
-        }
-        // ---- visited entries that fall off a frontier that is still not full can come back:
-        // remember them (see file header).  Once full, nothing dropped can ever re-enter. ----
-        if (f_new == beam) {
-          ndrop = 0;
-        } else if (P.cut_enabled && !first) {
-          for (uint32_t e0 = 0; e0 < f_old; e0 += PANN_WAVE) {
-            const uint32_t e = e0 + lane;
-            bool lost = false;
-            uint64_t key = 0;
-            if (e < f_old && Fv[e] == 1) {
-              key = F[e];
+            if (e < f) {
+              const uint64_t key = F[e];
               uint32_t below = 0;
               for (uint32_t i = 0; i < c; i++) below += (C[i] < key) ? 1u : 0u;
-              lost = (e + below) >= f_new;
+              const uint32_t pos = e + below;
+              if (pos < beam) { NF[pos] = key; NFv[pos] = Fv[e]; }
             }
-            const uint64_t lm = __ballot(lost);
-            if (lost) {
-              const uint32_t at = ndrop + lanes_below(lm, lane);
-              if (at < P.dcap) DL[at] = key; else atomicOr(P.status, 2u);
-            }
-            ndrop = min(ndrop + (uint32_t)__popcll(lm), P.dcap);
           }
-          // entries already listed (flag 2) stay listed; nothing to do for them
-          __builtin_amdgcn_s_waitcnt(0);   // dropped-list stores visible to this wave's later loads
+          __syncthreads();
+          const uint32_t f_old = f;
+          uint32_t f_new = min(f_old + nvalid, beam);   // :185
+          // ---- cut-prune (:190-195) ----
+          if (!first && P.cut_enabled && f_new > P.k) {
+            const float dk = key_dist(NF[P.k]);
+            const float thr = (float)(P.cut * (double)dk);
+            const uint64_t thr_key = (uint64_t)f2ord(thr) << 32;   // pair{0, thr}: kept iff key <= thr_key
+            uint32_t ub = 0;
+            for (uint32_t e0 = 0; e0 < f_new; e0 += PANN_WAVE) {
+              const uint32_t e = e0 + lane;
+              ub += __popcll(__ballot(e < f_new && NF[e] <= thr_key));
+            }
+            f_new = max(ub, f_old);
+          }
+          // ---- visited entries that fall off a frontier that is still not full can come back:
+          // remember them (see file header).  Once full, nothing dropped can ever re-enter. ----
+          if (f_new == beam) {
+            ndrop = 0;
+          } else if (P.cut_enabled && !first) {
+            for (uint32_t e0 = 0; e0 < f_old; e0 += PANN_WAVE) {
+              const uint32_t e = e0 + lane;
+              bool lost = false;
+              uint64_t key = 0;
+              if (e < f_old && Fv[e] == 1) {
+                key = F[e];
+                uint32_t below = 0;
+                for (uint32_t i = 0; i < c; i++) below += (C[i] < key) ? 1u : 0u;
+                lost = (e + below) >= f_new;
+              }
+              const uint64_t lm = __ballot(lost);
+              if (lost) {
+                const uint32_t at = ndrop + lanes_below(lm, lane);
+                if (at < P.dcap) DL[at] = key; else atomicOr(P.status, 2u);
+              }
+              ndrop = min(ndrop + (uint32_t)__popcll(lm), P.dcap);
+            }
+            // entries already listed (flag 2) stay listed; nothing to do for them
+            __builtin_amdgcn_s_waitcnt(0);   // dropped-list stores visible to this wave's later loads
+          }
+          // visited entries with flag 2 that stay in the frontier keep flag 2 (== visited)
+          { uint64_t* t = F; F = NF; NF = t; uint8_t* tv = Fv; Fv = NFv; NFv = tv; }
+          f = f_new;
+          c = 0;                      // candidates.clear() (:182)
+          __syncthreads();
+          if constexpr (B64) {   // reload the registers from the (swapped) LDS arrays
+            fkey = (lane < (int)f) ? F[lane] : KEY_INF;
+            fflag = (lane < (int)f) ? (uint32_t)Fv[lane] : 0u;
+            __syncthreads();
+          }
         }
-        // visited entries with flag 2 that stay in the frontier keep flag 2 (== visited)
-        { uint64_t* t = F; F = NF; NF = t; uint8_t* tv = Fv; Fv = NFv; NFv = tv; }
-        f = f_new;
-        c = 0;                      // candidates.clear() (:182)
-        __syncthreads();
       }
+      PANN_STAMP(4);     // merge (or nothing when skipped)
       first = false;
     }
 
@@ -343,10 +475,14 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_kernel(BSParams P) {
     const size_t qo = (size_t)qi * P.out.out_k;
     for (uint32_t j = lane; j < P.out.out_k; j += PANN_WAVE) {
       const bool ok = j < f;
-      const uint64_t key = ok ? F[j] : 0ull;
+      uint64_t key = 0ull;
+      if (ok) key = B64 ? fkey : F[j];          // B64: out_k <= beam <= 64, so j == lane
       if (P.out.ids) P.out.ids[qo + j] = ok ? key_id(key) : SENTINEL;
       if (P.out.dists) P.out.dists[qo + j] = ok ? key_dist(key) : __builtin_inff();
     }
+#ifdef PANN_STAMPS
+    if (lane == 0 && P.stamps) for (int i = 0; i < 8; i++) P.stamps[(size_t)qi * 8 + i] = stamp_sum[i];
+#endif
     if (lane == 0) {
       if (P.out.frontier_size) P.out.frontier_size[qi] = f;
       if (P.out.visited_count) P.out.visited_count[qi] = nvis;
@@ -360,6 +496,199 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_kernel(BSParams P) {
       if (lane == 0) qi = atomicAdd(P.work_counter, 1u);
       qi = __builtin_amdgcn_readfirstlane(qi);
     }
+  }
+}
+
+// =============================================================================================
+// beam <= 64 specialisation: the frontier lives in REGISTERS (lane e <-> entry e: key + visited
+// flag).  Head scan = one ballot, cutoff = one readlane, every merge = loops of readlane/ballot
+// steps over <= 64 candidates at a time (top-beam of a union is associative, so candidate chunks
+// are merged one after the other; cut-prune runs once at the end).  LDS per query shrinks to the
+// filter (4 KB) + a 64-entry scatter scratch + the candidate list: 5.2 KB -> 31 queries per CU.
+// =============================================================================================
+template <int DT, int METRIC, int LPC, bool NCH1>
+__global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES) beam_search_b64_kernel(BSParams P) {
+  const int lane = threadIdx.x;
+  extern __shared__ __align__(16) uint8_t smem[];
+  uint64_t* S = reinterpret_cast<uint64_t*>(smem);          // [64] merge scatter scratch; first 256 B double as Pl
+  uint64_t* C = S + 64;                                     // [ccap] candidates (unsorted)
+  uint8_t* Sv = reinterpret_cast<uint8_t*>(C + P.ccap);     // [64] flags of the scatter scratch
+  uint4* qlds = reinterpret_cast<uint4*>(Sv + 64);          // [nch*LPC] query (generic variant)
+  uint32_t* H = reinterpret_cast<uint32_t*>(qlds + (NCH1 ? 0 : P.nch * LPC));  // [1<<bits]
+  uint32_t* Pl = reinterpret_cast<uint32_t*>(S);            // [64] filter survivors of one row chunk
+
+  const uint32_t hsize = 1u << P.bits, hmask = hsize - 1u;
+  const uint32_t beam = P.beam;
+  const uint32_t BIG_ORD = f2ord(2147483648.0f);            // (:152)
+  const uint32_t qi = blockIdx.x;
+
+  for (uint32_t i = lane; i < hsize; i += PANN_WAVE) H[i] = SENTINEL;       // :53
+  const int64_t self = P.query_ids ? (int64_t)P.query_ids[qi] : -1;
+  const uint8_t* qrow = P.query_ids ? P.points + (uint64_t)self * P.pstride : P.queries + (uint64_t)qi * P.qstride;
+  QReg<DT> qreg{};
+  load_query<DT, LPC, NCH1>(qrow, P.dbytes, P.nch, qreg, qlds, lane);
+  __syncthreads();
+
+  uint32_t f = 0, c = 0, nvis = 0, dcmps = P.nstarts, degsum = 0, ndrop = 0;
+  uint64_t fkey = KEY_INF;
+  uint32_t fflag = 0;
+  uint64_t* DL = P.dropped + (size_t)qi * P.dcap;
+#ifdef PANN_STAMPS
+  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
+
+  // ---- start points (:66-70); nstarts <= 64 here ----
+  {
+    const bool act = lane < (int)P.nstarts;
+    const uint32_t a = act ? P.starts[lane] : 0u;
+    (void)filter_update<true>(H, hmask, act, a, lane);
+    if (act) Pl[lane] = a;
+    __syncthreads();
+    c = gather_distances<DT, METRIC, LPC, NCH1, 4>(P, qreg, qlds, Pl, P.nstarts, 0xFFFFFFFFu, C, c, lane);
+    __syncthreads();
+  }
+
+  bool first = true;
+  for (;;) {
+    bool do_merge = first;
+    if (!first) {
+      // ---- next vertex: first unvisited frontier entry (:107-109) ----
+      const uint64_t um = __ballot(lane < (int)f && fflag == 0);
+      if (um == 0ull || nvis >= P.limit) break;
+      const int cur_idx = __ffsll((unsigned long long)um) - 1;
+      const bool more_unvisited = (um & (um - 1)) != 0ull;       // offset + 1 < remain (:165)
+      PANN_STAMP(0);
+      const uint64_t cur_key = readlane64(fkey, cur_idx);
+      const uint32_t cur = key_id(cur_key);
+      if (lane == cur_idx) fflag = 1;                            // visited.insert(current) (:112-114)
+      if (lane == 0 && P.out.visited_cap) {
+        if (nvis < P.out.visited_cap) {
+          if (P.out.visited_ids) P.out.visited_ids[(size_t)qi * P.out.visited_cap + nvis] = cur;
+          if (P.out.visited_dists) P.out.visited_dists[(size_t)qi * P.out.visited_cap + nvis] = key_dist(cur_key);
+        } else {
+          atomicOr(P.status, 1u);
+        }
+      }
+      nvis++;
+      uint32_t cutoff_ord = BIG_ORD;                             // :150-152
+      if (f == beam) cutoff_ord = (uint32_t)(readlane64(fkey, (int)f - 1) >> 32);
+
+      const uint32_t* row = P.graph + (size_t)cur * P.gstride;
+      for (uint32_t i0 = 0; i0 < P.gstride; i0 += PANN_WAVE) {
+        const uint32_t i = i0 + lane;
+        uint32_t a = SENTINEL;
+        if (i < P.gstride) a = row[i];
+        const bool act = (a != SENTINEL) && (i < P.degree_limit);
+        const uint64_t am = __ballot(act);
+        PANN_STAMP(1);
+        if (am == 0ull) break;
+        degsum += __popcll(am);
+        const bool seen = filter_update<true>(H, hmask, act, a, lane);
+        const bool keep = act && !seen && ((int64_t)a != self);   // :133
+        const uint64_t km = __ballot(keep);
+        const uint32_t m = __popcll(km);
+        if (keep) Pl[lanes_below(km, lane)] = a;
+        dcmps += m;
+        __syncthreads();
+        PANN_STAMP(2);
+        if (m) c = gather_distances<DT, METRIC, LPC, NCH1, PANN_GU>(P, qreg, qlds, Pl, m, cutoff_ord, C, c, lane);
+        __syncthreads();
+        PANN_STAMP(3);
+      }
+      const bool skip = (c == 0) || (P.skip_enabled && c < beam / 8 && more_unvisited);   // :162-168
+      do_merge = !skip;
+    }
+    if (do_merge) {
+      const uint32_t f_old = f;
+      const bool track = P.cut_enabled && !first;
+      uint32_t lt = 0;                                           // tentative appends to the dropped list
+      for (uint32_t c0 = 0; c0 < c; c0 += PANN_WAVE) {           // sort+unique(C) U frontier, trimmed (:173-185)
+        const uint32_t cc = min(c - c0, (uint32_t)PANN_WAVE);
+        const uint64_t ckey = (lane < (int)cc) ? C[c0 + lane] : KEY_INF;
+        const bool fl = lane < (int)f;
+        uint32_t myp = 0, rank_c = 0, below_f = 0;
+        uint64_t live_mask = 0;
+        for (uint32_t i = 0; i < cc; i++) {
+          const uint64_t kk = readlane64(ckey, (int)i);
+          const uint64_t ltm = __ballot(fl && fkey < kk);
+          const uint64_t eqm = __ballot(fl && fkey == kk);               // already in the frontier (set_union)
+          const uint64_t dupm = __ballot(lane < (int)i && ckey == kk);   // duplicate (std::unique)
+          if (eqm == 0ull && dupm == 0ull) {
+            live_mask |= 1ull << i;
+            if (lane == (int)i) myp = __popcll(ltm);
+            rank_c += (kk < ckey) ? 1u : 0u;
+            below_f += (kk < fkey) ? 1u : 0u;
+          }
+        }
+        const uint32_t nvalid = __popcll(live_mask);
+        const bool clive = (lane < (int)cc) && ((live_mask >> lane) & 1ull);
+        const uint32_t cpos = rank_c + myp, fpos = (uint32_t)lane + below_f;
+        if (clive && cpos < beam) {
+          uint32_t flag = 0u;   // re-entry of an already visited vertex (only while the frontier is not full)
+          for (uint32_t t = 0; t < ndrop; t++)
+            flag |= (__hip_atomic_load(DL + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ckey) ? 2u : 0u;
+          S[cpos] = ckey; Sv[cpos] = (uint8_t)flag;
+        }
+        if (fl && fpos < beam) { S[fpos] = fkey; Sv[fpos] = (uint8_t)fflag; }
+        if (track) {            // visited entries pushed past the beam by this chunk
+          const bool lost = fl && fflag == 1u && fpos >= beam;
+          const uint64_t lm = __ballot(lost);
+          if (lost) {
+            const uint32_t at = ndrop + lt + lanes_below(lm, lane);
+            if (at < P.dcap) DL[at] = fkey; else atomicOr(P.status, 2u);
+          }
+          lt += __popcll(lm);
+        }
+        __syncthreads();
+        f = min(f + nvalid, beam);
+        fkey = (lane < (int)f) ? S[lane] : KEY_INF;
+        fflag = (lane < (int)f) ? (uint32_t)Sv[lane] : 0u;
+        __syncthreads();
+      }
+      uint32_t f_new = f;
+      if (!first && P.cut_enabled && f_new > P.k) {              // cut-prune (:190-195)
+        const float dk = key_dist(readlane64(fkey, (int)P.k));
+        const float thr = (float)(P.cut * (double)dk);
+        const uint64_t thr_key = (uint64_t)f2ord(thr) << 32;     // pair{0, thr}: kept iff key <= thr_key
+        const uint32_t ub = __popcll(__ballot(lane < (int)f_new && fkey <= thr_key));
+        f_new = max(ub, f_old);
+      }
+      if (f_new == beam) {
+        ndrop = 0;                                               // a full frontier never re-admits anything
+      } else if (track) {
+        const bool lost = lane >= (int)f_new && lane < (int)f && fflag == 1u;
+        const uint64_t lm = __ballot(lost);
+        if (lost) {
+          const uint32_t at = ndrop + lt + lanes_below(lm, lane);
+          if (at < P.dcap) DL[at] = fkey; else atomicOr(P.status, 2u);
+        }
+        lt += __popcll(lm);
+        ndrop = min(ndrop + lt, P.dcap);
+        if (lt) __builtin_amdgcn_s_waitcnt(0);
+      }
+      f = f_new;
+      if (lane >= (int)f) { fkey = KEY_INF; fflag = 0u; }
+      c = 0;                                                     // candidates.clear() (:182)
+    }
+    PANN_STAMP(4);
+    first = false;
+  }
+
+  const size_t qo = (size_t)qi * P.out.out_k;
+  if (lane < (int)P.out.out_k) {                                 // out_k <= beam <= 64
+    const bool ok = lane < (int)f;
+    if (P.out.ids) P.out.ids[qo + lane] = ok ? key_id(fkey) : SENTINEL;
+    if (P.out.dists) P.out.dists[qo + lane] = ok ? key_dist(fkey) : __builtin_inff();
+  }
+#ifdef PANN_STAMPS
+  if (lane == 0 && P.stamps) for (int i = 0; i < 8; i++) P.stamps[(size_t)qi * 8 + i] = stamp_sum[i];
+#endif
+  if (lane == 0) {
+    if (P.out.frontier_size) P.out.frontier_size[qi] = f;
+    if (P.out.visited_count) P.out.visited_count[qi] = nvis;
+    if (P.out.dist_cmps) P.out.dist_cmps[qi] = dcmps;
+    if (P.out.degree_sum) P.out.degree_sum[qi] = degsum;
   }
 }
 
@@ -386,7 +715,7 @@ static uint32_t filter_bits(int64_t beam) {  // :52
 }
 
 struct Plan {
-  uint32_t bits, bcap, ccap, deg_eff, dcap, lds_bytes; bool hash_lds; uint32_t slots;
+  uint32_t bits, bcap, ccap, deg_eff, dcap, lds_bytes; bool hash_lds; uint32_t slots; bool b64;
 };
 
 static Plan make_plan(const DeviceIndex& ix, const SearchArgs& a) {
@@ -406,6 +735,11 @@ static Plan make_plan(const DeviceIndex& ix, const SearchArgs& a) {
   p.hash_lds = (hbytes <= 16384) && (fixed + hbytes <= 64 * 1024);
   p.lds_bytes = (uint32_t)(fixed + (p.hash_lds ? hbytes : 0));
   p.slots = 256 * 8;
+  p.b64 = p.hash_lds && p.bcap == 64;
+  if (p.b64) {   // register-frontier kernel: scratch[64] + candidates (exact, 8-entry granules) + flags + query + filter
+    p.ccap = (std::max<uint32_t>(beam / 8 + p.deg_eff, a.nstarts) + 7) / 8 * 8;
+    p.lds_bytes = (uint32_t)(64 * 8 + (size_t)p.ccap * 8 + 64 + (nch1 ? 0 : (size_t)ix.nch * ix.lpc * 16) + hbytes);
+  }
   return p;
 }
 
@@ -419,13 +753,16 @@ size_t search_workspace_bytes(const DeviceIndex& ix, const SearchArgs& a) {
 
 template <int DT, int METRIC, int LPC, bool NCH1>
 static hipError_t launch_variant(const BSParams& P, const Plan& p, hipStream_t stream) {
-  if (p.hash_lds) {
-    auto kern = beam_search_kernel<DT, METRIC, LPC, NCH1, true>;
+  if (p.b64) {   // frontier in registers
+    auto kern = beam_search_b64_kernel<DT, METRIC, LPC, NCH1>;
+    hipLaunchKernelGGL(kern, dim3(P.nq), dim3(PANN_WAVE), p.lds_bytes, stream, P);
+  } else if (p.hash_lds) {
+    auto kern = beam_search_kernel<DT, METRIC, LPC, NCH1, true, false>;
     if (p.lds_bytes > 48 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     hipLaunchKernelGGL(kern, dim3(P.nq), dim3(PANN_WAVE), p.lds_bytes, stream, P);
   } else {
-    auto kern = beam_search_kernel<DT, METRIC, LPC, NCH1, false>;
+    auto kern = beam_search_kernel<DT, METRIC, LPC, NCH1, false, false>;
     if (p.lds_bytes > 48 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     const uint32_t grid = (uint32_t)std::min<uint64_t>(P.nq, p.slots);
@@ -481,6 +818,12 @@ int launch_beam_search(const DeviceIndex& ix, const SearchArgs& a, void* ws, siz
   P.dropped = (uint64_t*)(w + 256); P.dcap = p.dcap;
   P.hash_global = p.hash_lds ? nullptr : (uint32_t*)(w + 256 + (size_t)a.nq * p.dcap * 8);
   P.out = a.out;
+  P.stamps = nullptr;
+#ifdef PANN_STAMPS
+  static unsigned long long* d_stamps = nullptr; static size_t stamps_cap = 0;
+  if (stamps_cap < a.nq) { if (d_stamps) (void)hipFree(d_stamps); (void)hipMalloc((void**)&d_stamps, a.nq * 64); stamps_cap = a.nq; }
+  P.stamps = d_stamps;
+#endif
   PANN_HIP(hipMemsetAsync(w, 0, 256, stream));
 
   hipError_t e = hipErrorInvalidValue;
@@ -491,6 +834,18 @@ int launch_beam_search(const DeviceIndex& ix, const SearchArgs& a, void* ws, siz
   PANN_DISPATCH(PANN_F16, PANN_L2) PANN_DISPATCH(PANN_F16, PANN_MIPS)
 #undef PANN_DISPATCH
   if (e != hipSuccess) return hip_fail(e, "beam_search_kernel launch");
+#ifdef PANN_STAMPS
+  if (getenv("PANN_STAMPS_PRINT") && a.nq >= 1000) {
+    (void)hipStreamSynchronize(stream);
+    std::vector<unsigned long long> h(a.nq * 8);
+    (void)hipMemcpy(h.data(), P.stamps, a.nq * 64, hipMemcpyDeviceToHost);
+    double sum[8] = {0}; for (size_t q = 0; q < a.nq; q++) for (int i = 0; i < 8; i++) sum[i] += (double)h[q * 8 + i];
+    double tot = 0; for (int i = 0; i < 5; i++) tot += sum[i];
+    fprintf(stderr, "[stamps] per-query cycles: head %.0f row %.0f filter %.0f gather %.0f merge %.0f total %.0f  (shares %.1f%% %.1f%% %.1f%% %.1f%% %.1f%%)\n",
+            sum[0] / a.nq, sum[1] / a.nq, sum[2] / a.nq, sum[3] / a.nq, sum[4] / a.nq, tot / a.nq, 100 * sum[0] / tot, 100 * sum[1] / tot,
+            100 * sum[2] / tot, 100 * sum[3] / tot, 100 * sum[4] / tot);
+  }
+#endif
   return PANN_OK;
 }
 
