@@ -37,6 +37,9 @@ namespace pann {
 #ifndef PANN_MINWAVES
 #define PANN_MINWAVES 1
 #endif
+#ifndef PANN_MINWAVES_B64
+#define PANN_MINWAVES_B64 7   /* <= 72 VGPRs: 7 waves per SIMD = 28 queries per CU (6, 7 and 8 measure the same) */
+#endif
 #ifdef PANN_STAMPS
 #define PANN_STAMP(slot)                                                                        \
   do {                                                                                          \
@@ -155,11 +158,8 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
   return ((uint64_t)hi << 32) | lo;
 }
 
-// B64: beam <= 64 (and <= 64 start points): the frontier lives in REGISTERS, lane e <-> entry e
-// (key + visited flag); the head scan is one ballot, the cutoff one readlane, and a merge with
-// <= 64 candidates is a loop of readlane/ballot steps with no LDS round trip per step.  Larger
-// merges (only while the frontier is still filling) spill to the LDS arrays and take the generic path.
-template <int DT, int METRIC, int LPC, bool NCH1, bool HASH_LDS, bool B64>
+// Generic kernel: any beam (frontier in LDS), filter in LDS or in HBM scratch.
+template <int DT, int METRIC, int LPC, bool NCH1, bool HASH_LDS>
 __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES) beam_search_kernel(BSParams P) {
   const int lane = threadIdx.x;
   extern __shared__ __align__(16) uint8_t smem[];
@@ -198,8 +198,6 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES) beam_search_kernel(B
     hsync<HASH_LDS>();
 
     uint32_t f = 0;        // frontier size
-    uint64_t fkey = KEY_INF;   // B64: this lane's frontier entry
-    uint32_t fflag = 0;        // B64: its visited flag (0 / 1 / 2)
     uint32_t c = 0;        // accumulated candidates
     uint32_t nvis = 0;     // num_visited
     uint32_t dcmps = P.nstarts;  // dist_cmps == full_dist_cmps (:83-84)
@@ -233,30 +231,19 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES) beam_search_kernel(B
         // ---- next vertex: first unvisited frontier entry (:107-109) ----
         int cur_idx = -1;
         uint32_t unv_total = 0;
-        uint64_t cur_key;
-        if constexpr (B64) {
-          const uint64_t um = __ballot(lane < (int)f && fflag == 0);
-          unv_total = __popcll(um);
-          if (um) cur_idx = __ffsll((unsigned long long)um) - 1;
-          if (cur_idx < 0 || nvis >= P.limit) break;
-          PANN_STAMP(0);   // head scan
-          cur_key = readlane64(fkey, cur_idx);
-          if (lane == cur_idx) fflag = 1;
-        } else {
-          for (uint32_t e0 = 0; e0 < f; e0 += PANN_WAVE) {
-            const uint32_t e = e0 + lane;
-            const uint64_t um = __ballot(e < f && Fv[e] == 0);
-            if (cur_idx < 0 && um) cur_idx = (int)e0 + __ffsll((unsigned long long)um) - 1;
-            unv_total += __popcll(um);
-          }
-          if (cur_idx < 0 || nvis >= P.limit) break;
-          PANN_STAMP(0);   // head scan
-          cur_key = F[cur_idx];
+        for (uint32_t e0 = 0; e0 < f; e0 += PANN_WAVE) {
+          const uint32_t e = e0 + lane;
+          const uint64_t um = __ballot(e < f && Fv[e] == 0);
+          if (cur_idx < 0 && um) cur_idx = (int)e0 + __ffsll((unsigned long long)um) - 1;
+          unv_total += __popcll(um);
         }
+        if (cur_idx < 0 || nvis >= P.limit) break;
+        PANN_STAMP(0);   // head scan
+        const uint64_t cur_key = F[cur_idx];
         const uint32_t cur = key_id(cur_key);
         // ---- visited.insert(current) (:112-114) ----
         if (lane == 0) {
-          if constexpr (!B64) Fv[cur_idx] = 1;
+          Fv[cur_idx] = 1;
           if (P.out.visited_cap) {
             if (nvis < P.out.visited_cap) {
               if (P.out.visited_ids) P.out.visited_ids[(size_t)qi * P.out.visited_cap + nvis] = cur;
@@ -270,7 +257,7 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES) beam_search_kernel(B
         const bool more_unvisited = unv_total > 1;         // offset + 1 < remain (:165)
         const bool full = (f == beam);                      // :115
         uint32_t cutoff_ord = BIG_ORD;                      // :150-152
-        if (full) cutoff_ord = B64 ? (uint32_t)(readlane64(fkey, (int)f - 1) >> 32) : (uint32_t)(F[f - 1] >> 32);
+        if (full) cutoff_ord = (uint32_t)(F[f - 1] >> 32);
 
         // ---- adjacency row: lane i <- slot i; degree = number of non-sentinel slots ----
         const uint32_t* row = P.graph + (size_t)cur * P.gstride;
@@ -301,71 +288,7 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES) beam_search_kernel(B
         do_merge = !skip;
       }
       if (do_merge) {
-        bool generic = true;
-        if constexpr (B64) {
-          if (c <= (uint32_t)PANN_WAVE) {
-            generic = false;
-            // ============ register merge: sort+unique(C), set_union with F, trim (:173-185) ============
-            const uint64_t ckey = (lane < (int)c) ? C[lane] : KEY_INF;
-            const bool fl = lane < (int)f;
-            uint32_t myp = 0, rank_c = 0, below_f = 0;
-            uint64_t live_mask = 0;
-            for (uint32_t i = 0; i < c; i++) {
-              const uint64_t kk = readlane64(ckey, (int)i);
-              const uint64_t ltm = __ballot(fl && fkey < kk);                 // frontier entries below candidate i
-              const uint64_t eqm = __ballot(fl && fkey == kk);                // already in the frontier (set_union)
-              const uint64_t dupm = __ballot(lane < (int)i && ckey == kk);    // duplicate of an earlier candidate (std::unique)
-              if (eqm == 0ull && dupm == 0ull) {
-                live_mask |= 1ull << i;
-                if (lane == (int)i) myp = __popcll(ltm);
-                rank_c += (kk < ckey) ? 1u : 0u;
-                below_f += (kk < fkey) ? 1u : 0u;
-              }
-            }
-            const uint32_t nvalid = __popcll(live_mask);
-            const bool clive = (lane < (int)c) && ((live_mask >> lane) & 1ull);
-            const uint32_t cpos = rank_c + myp, fpos = (uint32_t)lane + below_f;
-            if (clive && cpos < beam) {
-              uint32_t flag = 0u;   // re-entry of an already visited vertex? (only while not full)
-              for (uint32_t t = 0; t < ndrop; t++)
-                flag |= (__hip_atomic_load(DL + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ckey) ? 2u : 0u;
-              F[cpos] = ckey; Fv[cpos] = (uint8_t)flag;
-            }
-            if (fl && fpos < beam) { F[fpos] = fkey; Fv[fpos] = (uint8_t)fflag; }
-            __syncthreads();
-            const uint32_t f_old = f;
-            uint32_t f_new = min(f_old + nvalid, beam);   // :185
-            const uint64_t nkey = (lane < (int)f_new) ? F[lane] : KEY_INF;
-            const uint32_t nflag = (lane < (int)f_new) ? (uint32_t)Fv[lane] : 0u;
-            if (!first && P.cut_enabled && f_new > P.k) {  // cut-prune (:190-195)
-              const float dk = key_dist(readlane64(nkey, (int)P.k));
-              const float thr = (float)(P.cut * (double)dk);
-              const uint64_t thr_key = (uint64_t)f2ord(thr) << 32;
-              const uint32_t ub = __popcll(__ballot(lane < (int)f_new && nkey <= thr_key));
-              f_new = max(ub, f_old);
-            }
-            if (f_new == beam) {
-              ndrop = 0;
-            } else if (P.cut_enabled && !first) {
-              const bool lost = fl && fflag == 1u && fpos >= f_new;
-              const uint64_t lm = __ballot(lost);
-              if (lost) {
-                const uint32_t at = ndrop + lanes_below(lm, lane);
-                if (at < P.dcap) DL[at] = fkey; else atomicOr(P.status, 2u);
-              }
-              ndrop = min(ndrop + (uint32_t)__popcll(lm), P.dcap);
-              if (lm) __builtin_amdgcn_s_waitcnt(0);
-            }
-            fkey = nkey; fflag = nflag;
-            f = f_new;
-            c = 0;
-            __syncthreads();
-          } else {
-            if (lane < (int)f) { F[lane] = fkey; Fv[lane] = (uint8_t)fflag; }   // spill for the generic path
-            __syncthreads();
-          }
-        }
-        if (generic) {
+        {
           // ================= merge: sort+unique(C), set_union with F, trim (:173-185) =========
           // A1: kill duplicates (same id <=> same key) and entries already in F; remember rank in F
           for (uint32_t j0 = 0; j0 < c; j0 += PANN_WAVE) {
@@ -460,11 +383,6 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES) beam_search_kernel(B
           f = f_new;
           c = 0;                      // candidates.clear() (:182)
           __syncthreads();
-          if constexpr (B64) {   // reload the registers from the (swapped) LDS arrays
-            fkey = (lane < (int)f) ? F[lane] : KEY_INF;
-            fflag = (lane < (int)f) ? (uint32_t)Fv[lane] : 0u;
-            __syncthreads();
-          }
         }
       }
       PANN_STAMP(4);     // merge (or nothing when skipped)
@@ -476,7 +394,7 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES) beam_search_kernel(B
     for (uint32_t j = lane; j < P.out.out_k; j += PANN_WAVE) {
       const bool ok = j < f;
       uint64_t key = 0ull;
-      if (ok) key = B64 ? fkey : F[j];          // B64: out_k <= beam <= 64, so j == lane
+      if (ok) key = F[j];
       if (P.out.ids) P.out.ids[qo + j] = ok ? key_id(key) : SENTINEL;
       if (P.out.dists) P.out.dists[qo + j] = ok ? key_dist(key) : __builtin_inff();
     }
@@ -507,7 +425,7 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES) beam_search_kernel(B
 // filter (4 KB) + a 64-entry scatter scratch + the candidate list: 5.2 KB -> 31 queries per CU.
 // =============================================================================================
 template <int DT, int METRIC, int LPC, bool NCH1>
-__global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES) beam_search_b64_kernel(BSParams P) {
+__global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES_B64) beam_search_b64_kernel(BSParams P) {
   const int lane = threadIdx.x;
   extern __shared__ __align__(16) uint8_t smem[];
   uint64_t* S = reinterpret_cast<uint64_t*>(smem);          // [64] merge scatter scratch; first 256 B double as Pl
@@ -757,12 +675,12 @@ static hipError_t launch_variant(const BSParams& P, const Plan& p, hipStream_t s
     auto kern = beam_search_b64_kernel<DT, METRIC, LPC, NCH1>;
     hipLaunchKernelGGL(kern, dim3(P.nq), dim3(PANN_WAVE), p.lds_bytes, stream, P);
   } else if (p.hash_lds) {
-    auto kern = beam_search_kernel<DT, METRIC, LPC, NCH1, true, false>;
+    auto kern = beam_search_kernel<DT, METRIC, LPC, NCH1, true>;
     if (p.lds_bytes > 48 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     hipLaunchKernelGGL(kern, dim3(P.nq), dim3(PANN_WAVE), p.lds_bytes, stream, P);
   } else {
-    auto kern = beam_search_kernel<DT, METRIC, LPC, NCH1, false, false>;
+    auto kern = beam_search_kernel<DT, METRIC, LPC, NCH1, false>;
     if (p.lds_bytes > 48 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     const uint32_t grid = (uint32_t)std::min<uint64_t>(P.nq, p.slots);

@@ -74,7 +74,7 @@ template <int DT> struct QReg;          // 16 query bytes, converted once per qu
 template <> struct QReg<PANN_U8>  { uint4 raw; uint32_t qq; };   // qq = sum of squares of these 16 bytes
 template <> struct QReg<PANN_I8>  { uint4 raw; uint32_t qq; };
 template <> struct QReg<PANN_F32> { float f[4]; };
-template <> struct QReg<PANN_F16> { float f[8]; };
+template <> struct QReg<PANN_F16> { uint4 raw; };        // halves stay packed; widened inside v_fma_mix
 
 template <int DT> struct Acc;           // per-lane partial state
 template <> struct Acc<PANN_U8>  { uint32_t aa, aq; __device__ __forceinline__ void clear() { aa = 0; aq = 0; } };
@@ -106,32 +106,31 @@ __device__ __forceinline__ QReg<DT> make_qreg(const uint4& q) {
     r.f[0] = __uint_as_float(q.x); r.f[1] = __uint_as_float(q.y);
     r.f[2] = __uint_as_float(q.z); r.f[3] = __uint_as_float(q.w);
   } else {
-    half8 h; __builtin_memcpy(&h, &q, 16);
-#pragma unroll
-    for (int i = 0; i < 8; i++) r.f[i] = (float)h[i];
+    r.raw = q;
   }
   return r;
 }
 
-// q - (float)half(a, lo/hi): one v_fma_mix_f32 (f16 operand widened inside the FMA: a*(-1)+q, a
-// single rounding of the exact difference, i.e. bit-identical to cvt + sub)
+// (float)half(q) - (float)half(a), both taken from the lo or the hi half of their dword: one
+// v_fma_mix_f32 (f16 operands widened inside the FMA: a*(-1)+q, a single rounding of the exact
+// difference, i.e. bit-identical to cvt + cvt + sub)
 template <int HI>
-__device__ __forceinline__ float sub_widen_f16(uint32_t a_pair, float q) {
+__device__ __forceinline__ float sub_widen_f16(uint32_t a_pair, uint32_t q_pair) {
   float t;
   if constexpr (HI == 0)
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(t) : "v"(a_pair), "v"(q));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(t) : "v"(a_pair), "v"(q_pair));
   else
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t) : "v"(a_pair), "v"(q));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(t) : "v"(a_pair), "v"(q_pair));
   return t;
 }
-// acc + (float)half(a) * q   (MIPS term), same instruction
+// acc + (float)half(a) * (float)half(q)   (MIPS term), same instruction
 template <int HI>
-__device__ __forceinline__ float fma_widen_f16(uint32_t a_pair, float q, float acc) {
+__device__ __forceinline__ float fma_widen_f16(uint32_t a_pair, uint32_t q_pair, float acc) {
   float t;
   if constexpr (HI == 0)
-    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(t) : "v"(a_pair), "v"(q), "v"(acc));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "=v"(t) : "v"(a_pair), "v"(q_pair), "v"(acc));
   else
-    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t) : "v"(a_pair), "v"(q), "v"(acc));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "=v"(t) : "v"(a_pair), "v"(q_pair), "v"(acc));
   return t;
 }
 
@@ -174,14 +173,14 @@ __device__ __forceinline__ void dist_accum(Acc<DT>& acc, const uint4& a, const Q
       acc.s = __builtin_elementwise_fma(q23, a23, acc.s);
     }
   } else {  // PANN_F16: halves widened to f32 inside the FMA (exact), arithmetic is f32
-    const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+    const uint32_t w[4] = {a.x, a.y, a.z, a.w}, qw[4] = {q.raw.x, q.raw.y, q.raw.z, q.raw.w};
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       if constexpr (METRIC == PANN_L2) {
-        const float2v t{sub_widen_f16<0>(w[i], q.f[2 * i]), sub_widen_f16<1>(w[i], q.f[2 * i + 1])};
+        const float2v t{sub_widen_f16<0>(w[i], qw[i]), sub_widen_f16<1>(w[i], qw[i])};
         acc.s = __builtin_elementwise_fma(t, t, acc.s);
       } else {
-        acc.s = float2v{fma_widen_f16<0>(w[i], q.f[2 * i], acc.s.x), fma_widen_f16<1>(w[i], q.f[2 * i + 1], acc.s.y)};
+        acc.s = float2v{fma_widen_f16<0>(w[i], qw[i], acc.s.x), fma_widen_f16<1>(w[i], qw[i], acc.s.y)};
       }
     }
   }
