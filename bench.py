@@ -55,7 +55,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible and there is no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if "RANK" in os.environ:   # launched by torch.distributed.run (also with one rank: same code path)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)   # RCCL; used only for barriers + max-over-ranks
 
     # ---- synthetic SIFT-1M-shaped data: integer-valued in [0,255] (see datasets.sift_like) ----
@@ -155,7 +156,8 @@ def main():
             res["cpu_baseline"] = cpu_baseline(ix, Xf, Q.astype(np.float32), args)
         print(json.dumps(res), flush=True)
     ix.close()
-    if world > 1:
+    if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
 
 

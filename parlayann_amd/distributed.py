@@ -22,7 +22,7 @@ def shard_range(n, rank, world):
 
 
 def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()
 
 
@@ -37,7 +37,7 @@ def timed_steps(step, steps, warmup, sync=lambda: None, device=None):
         step()
     sync(); barrier()
     elapsed = time.perf_counter() - t0
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device or "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
