@@ -135,6 +135,13 @@ int pann_batch_search_dev(pann_index* idx, const void* d_queries, const uint32_t
                           uint32_t nstarts, const pann_query_params* qp,
                           const pann_search_out* d_out, void* stream);
 
+/* beamSearchRandom (beamSearch.h:309-351): like pann_batch_search, but every query has its OWN start
+ * vertices: starts is nq x nstarts.  (The reference draws one random start per query from
+ * parlay::random_generator; the caller supplies the draws here.)  Host pointers. */
+int pann_batch_search_per_query_starts(pann_index* idx, const void* queries, const uint32_t* query_ids, uint64_t nq,
+                                       uint64_t q_stride_bytes, const uint32_t* starts, uint32_t nstarts,
+                                       const pann_query_params* qp, const pann_search_out* out);
+
 /* ---- distances ------------------------------------------------------------------------------ */
 
 /* out[i] = distance(Points[a_ids[i]], Points[b_ids[i]]), i < m  (Point::distance). host pointers */

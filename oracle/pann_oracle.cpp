@@ -624,4 +624,100 @@ void pann_oracle_mips_i8_translate(const float* x, uint64_t n, uint32_t d, float
   }
 }
 
+
+// ---- HCNNG (clusterEdge.h:40-153, hcnng_index.h:102-281) with this build's explicit seeding rules
+// (DESIGN.md "Build determinism"): node RNG r: ith_rand(i) = mix(r + i), fork(i) = mix(mix(r) + i + 17),
+// tree t seeded with mix(mix(seed + t)); a split that leaves one side empty falls back to "halve".
+namespace {
+inline uint64_t hc_mix(uint64_t x) {
+  x += UINT64_C(0x9e3779b97f4a7c15);
+  x = (x ^ (x >> 30)) * UINT64_C(0xbf58476d1ce4e5b9);
+  x = (x ^ (x >> 27)) * UINT64_C(0x94d049bb133111eb);
+  return x ^ (x >> 31);
+}
+void hc_cluster(const Dataset& D, std::vector<uint32_t>& act, uint64_t rnd, size_t cluster_size,
+                std::vector<std::vector<uint32_t>>& leaves) {
+  if (act.size() <= cluster_size) { leaves.push_back(act); return; }          // clusterEdge.h:103-104
+  const size_t fi = hc_mix(rnd + 0) % act.size();                              // select_two_random :40-50
+  const size_t su = hc_mix(rnd + 1) % (act.size() - 1);
+  const size_t si = su < fi ? su : su + 1;
+  const uint32_t f = act[fi], s = act[si];
+  std::vector<uint32_t> a, b;
+  bool same = std::memcmp(D.row(f), D.row(s), (size_t)D.d * (D.dtype == DT_F32 ? 4 : D.dtype == DT_F16 ? 2 : 1)) == 0;   // Points[f] == Points[s] :107
+  if (!same) {
+    for (uint32_t id : act) {                                                  // :71-83
+      float df = D.dist_ids(id, f), ds = D.dist_ids(id, s);
+      if (df <= ds) a.push_back(id); else b.push_back(id);
+    }
+  }
+  if (same || a.empty() || b.empty()) {                                        // :108-115
+    a.clear(); b.clear();
+    for (size_t i = 0; i < act.size(); i++) (i < act.size() / 2 ? a : b).push_back(act[i]);
+  }
+  std::vector<uint32_t>().swap(act);
+  hc_cluster(D, a, hc_mix(hc_mix(rnd) + 0 + 17), cluster_size, leaves);       // rnd.fork(0) :85
+  hc_cluster(D, b, hc_mix(hc_mix(rnd) + 1 + 17), cluster_size, leaves);       // rnd.fork(1) :86
+}
+struct HcDS {   // hcnng_index.h:36-89 (incl. the use of rank[x] rather than rank[root])
+  std::vector<int> parent, rank;
+  explicit HcDS(size_t n) : parent(n), rank(n, 0) { for (size_t i = 0; i < n; i++) parent[i] = (int)i; }
+  int find(int x) { if (parent[x] != x) parent[x] = find(parent[x]); return parent[x]; }
+  void unite(int x, int y) {
+    int xr = find(x), yr = find(y), xk = rank[x], yk = rank[y];
+    if (xr == yr) return;
+    if (xk < yk) parent[xr] = yr; else { parent[yr] = xr; if (xk == yk) rank[xr]++; }
+  }
+  bool full() { int r = find(0); for (size_t i = 1; i < parent.size(); i++) if (find((int)i) != r) return false; return true; }
+};
+}  // namespace
+
+int pann_oracle_hcnng_build(const void* points, uint64_t n, uint32_t d, int dtype, uint64_t stride, int metric,
+                            uint32_t* graph, uint32_t maxdeg, long num_clusters, long cluster_size, long mst_deg,
+                            uint64_t seed, int nthreads) {
+  Dataset D{(const uint8_t*)points, n, d, dtype, stride, metric, graph, maxdeg};
+  const uint32_t m = 10;                                                       // hcnng_index.h:140
+  for (long t = 0; t < num_clusters; t++) {
+    std::vector<uint32_t> all(n);
+    for (uint64_t i = 0; i < n; i++) all[i] = (uint32_t)i;
+    std::vector<std::vector<uint32_t>> leaves;
+    hc_cluster(D, all, hc_mix(hc_mix(seed + (uint64_t)t)), (size_t)cluster_size, leaves);
+    parallel_for(0, leaves.size(), nthreads, [&](size_t li) {                 // MSTk :134-229
+      const std::vector<uint32_t>& ids = leaves[li];
+      const size_t N = ids.size();
+      if (N < 2) return;
+      struct E { float w; int i, j; };
+      std::vector<E> edges;
+      for (size_t i = 0; i < N; i++) {
+        std::vector<IdDist> v;
+        for (size_t j = 0; j < N; j++) if (j != i) v.push_back(IdDist{ids[j], D.dist_ids(ids[i], ids[j])});
+        size_t kk = std::min<size_t>(m, v.size());
+        std::partial_sort(v.begin(), v.begin() + kk, v.end(), less_id_dist);  // 10 nearest, ties by id
+        for (size_t t2 = 0; t2 < kk; t2++) {
+          int j = (int)(std::find(ids.begin(), ids.end(), v[t2].id) - ids.begin());
+          edges.push_back(E{v[t2].dist, std::min((int)i, j), std::max((int)i, j)});
+        }
+      }
+      auto lt = [](const E& a, const E& b) { return a.w < b.w || (a.w == b.w && (a.i < b.i || (a.i == b.i && a.j < b.j))); };
+      std::sort(edges.begin(), edges.end(), lt);                               // less_dup :183-201
+      edges.erase(std::unique(edges.begin(), edges.end(), [](const E& a, const E& b) { return a.w == b.w && a.i == b.i && a.j == b.j; }),
+                  edges.end());
+      HcDS ds(N);
+      std::vector<int> deg(N, 0);
+      for (size_t e = 0; e < edges.size(); e++) {                              // :208-226
+        const int a = edges[e].i, b = edges[e].j;
+        if (ds.find(a) != ds.find(b) && deg[a] < mst_deg && deg[b] < mst_deg) {
+          for (int dir = 0; dir < 2; dir++) {                                  // process_edges :117-131
+            uint32_t* row = graph + (uint64_t)ids[dir ? b : a] * (maxdeg + 1);
+            if (row[0] < maxdeg) { row[1 + row[0]] = ids[dir ? a : b]; row[0]++; }
+          }
+          deg[a]++; deg[b]++;
+          ds.unite(a, b);
+        }
+        if (e % N == 0 && ds.full()) break;
+      }
+    });
+  }
+  return 0;
+}
+
 }  // extern "C"

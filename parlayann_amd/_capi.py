@@ -64,6 +64,8 @@ SIGNATURES = {
     "pann_index_get_graph": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pann_batch_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
                                     C.c_uint32, C.POINTER(QueryParams), C.POINTER(SearchOut)]),
+    "pann_batch_search_per_query_starts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                                     C.c_void_p, C.c_uint32, C.POINTER(QueryParams), C.POINTER(SearchOut)]),
     "pann_batch_search_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
                                         C.c_uint32, C.POINTER(QueryParams), C.POINTER(SearchOut), C.c_void_p]),
     "pann_pair_distances": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),

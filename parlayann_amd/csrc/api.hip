@@ -289,13 +289,16 @@ int pann_batch_search_dev(pann_index* idx, const void* d_queries, const uint32_t
   return launch_beam_search(idx->ix, a, idx->ws.buf, idx->ws.bytes, (hipStream_t)stream);
 }
 
-int pann_batch_search(pann_index* idx, const void* queries, const uint32_t* query_ids, uint64_t nq,
-                      uint64_t q_stride_bytes, const uint32_t* starts, uint32_t nstarts,
-                      const pann_query_params* qp, const pann_search_out* out) {
+}  // extern "C"
+
+static int batch_search_host(pann_index* idx, const void* queries, const uint32_t* query_ids, uint64_t nq,
+                             uint64_t q_stride_bytes, const uint32_t* starts, uint32_t nstarts, int per_query,
+                             const pann_query_params* qp, const pann_search_out* out) {
   if (int rc = search_common_checks(idx, nq, qp, out)) return rc;
   if (!starts || nstarts == 0) { set_error("beam search expects at least one start point"); return PANN_ERR_BAD_ARG; }
   if ((queries == nullptr) == (query_ids == nullptr)) { set_error("pann_batch_search: exactly one of queries / query_ids must be given"); return PANN_ERR_BAD_ARG; }
-  for (uint32_t i = 0; i < nstarts; i++)
+  const uint64_t nst_total = per_query ? nq * nstarts : nstarts;
+  for (uint64_t i = 0; i < nst_total; i++)
     if (starts[i] >= idx->ix.n) { set_error("pann_batch_search: start point out of range"); return PANN_ERR_BAD_ARG; }
   if (query_ids)
     for (uint64_t i = 0; i < nq; i++)
@@ -316,8 +319,8 @@ int pann_batch_search(pann_index* idx, const void* queries, const uint32_t* quer
     PANN_HIP(hipMemcpyAsync(idx->stage[2].p, query_ids, nq * 4, hipMemcpyHostToDevice, st));
     d_qid = idx->stage[2].as<uint32_t>();
   }
-  if (int rc = idx->stage[3].ensure((size_t)nstarts * 4)) return rc;
-  PANN_HIP(hipMemcpyAsync(idx->stage[3].p, starts, (size_t)nstarts * 4, hipMemcpyHostToDevice, st));
+  if (int rc = idx->stage[3].ensure((size_t)nst_total * 4)) return rc;
+  PANN_HIP(hipMemcpyAsync(idx->stage[3].p, starts, (size_t)nst_total * 4, hipMemcpyHostToDevice, st));
   // device outputs
   pann_search_out d = *out;
   const size_t ok = out->out_k, vc = out->visited_cap;
@@ -341,7 +344,16 @@ int pann_batch_search(pann_index* idx, const void* queries, const uint32_t* quer
   d.visited_ids = (uint32_t*)p_vi; d.visited_dists = (float*)p_vd;
   if (!p_vi && !p_vd) d.visited_cap = 0;
 
-  int rc = pann_batch_search_dev(idx, d_q, d_qid, nq, q_stride_bytes, idx->stage[3].as<uint32_t>(), nstarts, qp, &d, st);
+  int rc;
+  {
+    SearchArgs a;
+    a.queries = (const uint8_t*)d_q; a.qstride = q_stride_bytes; a.query_ids = d_qid;
+    a.nq = nq; a.starts = idx->stage[3].as<uint32_t>(); a.nstarts = nstarts; a.starts_per_query = per_query;
+    a.k = qp->k; a.beam = qp->beam; a.limit = qp->limit; a.degree_limit = qp->degree_limit; a.cut = qp->cut;
+    a.out = d;
+    if ((rc = idx->ws.ensure(search_workspace_bytes(idx->ix, a)))) return rc;
+    rc = launch_beam_search(idx->ix, a, idx->ws.buf, idx->ws.bytes, st);
+  }
   if (rc) return rc;
   auto back = [&](void* host, void* dev, size_t bytes) -> hipError_t {
     if (!host || !dev || !bytes) return hipSuccess;
@@ -361,6 +373,20 @@ int pann_batch_search(pann_index* idx, const void* queries, const uint32_t* quer
   if (status & 1u) { set_error("pann_batch_search: visited list longer than visited_cap"); return PANN_ERR_OVERFLOW; }
   if (status & 2u) { set_error("pann_batch_search: internal dropped-list overflow"); return PANN_ERR_OVERFLOW; }
   return PANN_OK;
+}
+
+extern "C" {
+
+int pann_batch_search(pann_index* idx, const void* queries, const uint32_t* query_ids, uint64_t nq,
+                      uint64_t q_stride_bytes, const uint32_t* starts, uint32_t nstarts,
+                      const pann_query_params* qp, const pann_search_out* out) {
+  return batch_search_host(idx, queries, query_ids, nq, q_stride_bytes, starts, nstarts, 0, qp, out);
+}
+
+int pann_batch_search_per_query_starts(pann_index* idx, const void* queries, const uint32_t* query_ids, uint64_t nq,
+                                       uint64_t q_stride_bytes, const uint32_t* starts, uint32_t nstarts,
+                                       const pann_query_params* qp, const pann_search_out* out) {
+  return batch_search_host(idx, queries, query_ids, nq, q_stride_bytes, starts, nstarts, 1, qp, out);
 }
 
 

@@ -58,7 +58,7 @@ struct BSParams {
   const uint8_t* points; uint32_t pstride; uint32_t dbytes; uint32_t nch;
   const uint32_t* graph; uint32_t gstride; uint32_t max_deg;
   const uint8_t* queries; uint64_t qstride; const uint32_t* query_ids;
-  const uint32_t* starts; uint32_t nstarts;
+  const uint32_t* starts; uint32_t nstarts; uint32_t starts_stride;   // starts_stride: 0 shared, nstarts per query
   uint32_t nq;
   uint32_t k, beam, limit, degree_limit; double cut;
   uint32_t skip_enabled;   // QP.limit >= 2*beam (:163)
@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES) beam_search_kernel(B
     for (uint32_t s0 = 0; s0 < P.nstarts; s0 += PANN_WAVE) {
       const uint32_t i = s0 + lane;
       const bool act = i < P.nstarts;
-      const uint32_t a = act ? P.starts[i] : 0u;
+      const uint32_t a = act ? P.starts[(size_t)qi * P.starts_stride + i] : 0u;
       (void)filter_update<HASH_LDS>(H, hmask, act, a, lane);
       if (act) PANN_PL[lane] = a;
       __syncthreads();
@@ -459,7 +459,7 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES_B64) beam_search_b64_
   // ---- start points (:66-70); nstarts <= 64 here ----
   {
     const bool act = lane < (int)P.nstarts;
-    const uint32_t a = act ? P.starts[lane] : 0u;
+    const uint32_t a = act ? P.starts[(size_t)qi * P.starts_stride + lane] : 0u;
     (void)filter_update<true>(H, hmask, act, a, lane);
     if (act) Pl[lane] = a;
     __syncthreads();
@@ -724,7 +724,7 @@ int launch_beam_search(const DeviceIndex& ix, const SearchArgs& a, void* ws, siz
   P.points = ix.points; P.pstride = ix.pstride; P.dbytes = ix.dbytes; P.nch = ix.nch;
   P.graph = ix.graph; P.gstride = ix.gstride; P.max_deg = ix.max_deg;
   P.queries = a.queries; P.qstride = a.qstride; P.query_ids = a.query_ids;
-  P.starts = a.starts; P.nstarts = a.nstarts; P.nq = (uint32_t)a.nq;
+  P.starts = a.starts; P.nstarts = a.nstarts; P.starts_stride = a.starts_per_query ? a.nstarts : 0u; P.nq = (uint32_t)a.nq;
   P.k = (uint32_t)std::max<int64_t>(a.k, 0); P.beam = (uint32_t)a.beam;
   P.limit = (uint32_t)std::min<int64_t>(std::max<int64_t>(a.limit, 0), 0xFFFFFFFFll);
   P.degree_limit = p.deg_eff; P.cut = a.cut;

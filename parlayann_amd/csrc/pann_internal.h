@@ -36,6 +36,7 @@ struct SearchArgs {  // one batched beam search, everything device resident
   const uint32_t* query_ids;                 // base-point queries (or null)
   uint64_t nq;
   const uint32_t* starts; uint32_t nstarts;
+  int starts_per_query = 0;                  // starts is nq x nstarts (beamSearchRandom)
   int64_t k, beam, limit, degree_limit; double cut;
   pann_search_out out;
 };

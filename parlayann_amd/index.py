@@ -117,6 +117,9 @@ class DeviceIndex:
                         visited_ids=_ptr(res["visited_ids"]), visited_dists=_ptr(res["visited_dists"]),
                         visited_cap=visited_cap)
         starts = np.ascontiguousarray(starts, dtype=np.uint32)
+        per_query = starts.ndim == 2          # nq x nstarts: beamSearchRandom-style, one start set per query
+        if per_query and starts.shape[0] != nq:
+            raise ValueError("per-query starts must be nq x nstarts")
         q = qid = None
         stride = 0
         if queries is not None:
@@ -126,8 +129,8 @@ class DeviceIndex:
             stride = _row_stride(q)
         else:
             qid = np.ascontiguousarray(query_ids, dtype=np.uint32)
-        check(self._lib.pann_batch_search(self._h, _ptr(q), _ptr(qid), nq, stride, _ptr(starts), len(starts),
-                                          C.byref(qp), C.byref(out)))
+        fn = self._lib.pann_batch_search_per_query_starts if per_query else self._lib.pann_batch_search
+        check(fn(self._h, _ptr(q), _ptr(qid), nq, stride, _ptr(starts), starts.shape[-1], C.byref(qp), C.byref(out)))
         return res
 
     # ---- robustPrune (vamana/index.h:63-137), batched ----

@@ -197,3 +197,15 @@ class Oracle:
         x = np.ascontiguousarray(x, np.float32); out = np.empty(x.shape, np.int8)
         self.lib.pann_oracle_mips_i8_translate(_p(x), C.c_uint64(x.shape[0]), C.c_uint32(x.shape[1]), C.c_float(mv), _p(out))
         return out
+
+    def hcnng_build(self, points, num_clusters, cluster_size, mst_deg, seed=1, metric="l2", threads=None):
+        points = np.ascontiguousarray(points)
+        n, d = points.shape
+        maxdeg = num_clusters * mst_deg
+        graph = np.zeros((n, maxdeg + 1), np.uint32)
+        rc = self.lib.pann_oracle_hcnng_build(
+            _p(points), C.c_uint64(n), C.c_uint32(d), C.c_int(DT[points.dtype]), C.c_uint64(points.strides[0]),
+            C.c_int(_m(metric)), _p(graph), C.c_uint32(maxdeg), C.c_long(num_clusters), C.c_long(cluster_size),
+            C.c_long(mst_deg), C.c_uint64(seed), C.c_int(threads or self.threads))
+        assert rc == 0
+        return graph

@@ -166,3 +166,25 @@ def test_search_and_parse_sweep(oracle):
     assert buckets == sorted(buckets) and all(b <= r["recall"] for b, r in zip(buckets, best))
     assert by_beam[1000]["recall"] >= by_beam[10]["recall"]
     ix.close()
+
+
+@pytest.mark.parametrize("dtype,metric,d", [(np.uint8, "Euclidian", 128), (np.int8, "mips", 200), (np.float16, "Euclidian", 96)])
+def test_hcnng_build_identical_to_oracle(oracle, dtype, metric, d):
+    """host tree + Kruskal around the device calls (pivot split, leaf kNN) vs. the all-CPU oracle:
+    same seeding rules, integer-valued data -> the graphs must be identical, slot for slot."""
+    X = datasets.sift_like(5000, d, seed=1234, dtype=np.float32)
+    X = (X - 128).clip(-127, 127).astype(np.int8) if dtype == np.int8 else X.astype(dtype)
+    G = wrapper.hcnng_build(X, metric, 6, 200, 3, seed=9)
+    Go = oracle.hcnng_build(X, 6, 200, 3, seed=9, metric="l2" if metric == "Euclidian" else "mips")
+    np.testing.assert_array_equal(G, Go)
+
+
+def test_parlayannpy_dropin_names():
+    from parlayann_amd import _ParlayANNpy as m
+    for cls in ("FloatEuclidianIndex", "FloatMipsIndex", "UInt8EuclidianIndex", "UInt8MipsIndex", "Int8EuclidianIndex",
+                "Int8MipsIndex"):
+        assert hasattr(m, cls)
+    assert sum(1 for n in m.__all__ if n.startswith("build_")) == 24
+    assert m.defaults.ALPHA == 1.2 and m.defaults.GRAPH_DEGREE == 64 and m.defaults.BEAMWIDTH == 128
+    with pytest.raises(NotImplementedError):
+        m.build_hnsw_float_euclidian_index("Euclidian", "a", "b", 1, 2, 3.0, 4.0)

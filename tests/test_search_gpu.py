@@ -160,3 +160,18 @@ def test_graph_roundtrip_and_update_rows(oracle):
     g = ix.batch_search(Q, k=10, beam=64)
     _compare(o, g)
     ix.close()
+
+
+def test_per_query_starts_like_beamSearchRandom(oracle):
+    """beamSearch.h:309-351: one (random) start vertex per query."""
+    X, Q, G = _setup(oracle, 8000, 128, np.uint8, "l2")
+    ix = DeviceIndex(X, G)
+    rng = np.random.default_rng(3)
+    for nst, beam in ((1, 64), (3, 100)):
+        starts = np.stack([rng.choice(len(X), nst, replace=False) for _ in range(len(Q))]).astype(np.uint32)
+        g = ix.batch_search(Q, k=10, beam=beam, starts=starts)
+        for i in (0, 7, 100, len(Q) - 1):
+            o = oracle.batch_search(X, G, queries=Q[i:i + 1], k=10, beam=beam, starts=starts[i])
+            np.testing.assert_array_equal(o["ids"][0], g["ids"][i])
+            assert o["dist_cmps"][0] == g["dist_cmps"][i] and o["visited_count"][0] == g["visited_count"][i]
+    ix.close()
