@@ -99,3 +99,30 @@ def stitch_graph(local_rows, n, device=None):
     layout, ids already global), padded to the common shard height; returns the full [n, R+1] graph."""
     rows = all_gather_array(local_rows, device)
     return rows.reshape(-1, local_rows.shape[1])[:n]
+
+
+def hcnng_build_tree_parallel(build_tree, n, num_clusters, mst_deg, device=None):
+    """HCNNG over ranks: the cluster trees are independent
+    (clusterEdge.h:146-153), so rank r builds trees r, r+W, r+2W, ...; `build_tree(t)` returns tree
+    t's edges as an [n, mst_deg+1] slab (reference row layout: count, then <= mst_deg neighbours).
+    ONE all-gather of the slabs, then every rank concatenates each vertex's lists in tree order
+    t = 0, 1, 2, ... -- exactly the adjacency the single-process build appends (hcnng_index.h:117-131)."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    per = (num_clusters + world - 1) // world
+    w = mst_deg + 1
+    slab = np.zeros((n, per * w), np.uint32)
+    for j, t in enumerate(range(rank, num_clusters, world)):
+        g = np.asarray(build_tree(t), dtype=np.uint32)
+        assert g.shape == (n, w)
+        slab[:, j * w:(j + 1) * w] = g
+    slabs = all_gather_array(slab, device)                        # [W, n, per*(mst_deg+1)]
+    out = np.zeros((n, num_clusters * mst_deg + 1), np.uint32)
+    for t in range(num_clusters):
+        g = slabs[t % world][:, (t // world) * w:(t // world + 1) * w]
+        cnt = g[:, 0].astype(np.int64)
+        for j in range(mst_deg):
+            sel = np.nonzero(cnt > j)[0]
+            out[sel, 1 + out[sel, 0].astype(np.int64)] = g[sel, 1 + j]
+            out[sel, 0] += 1
+    return out

@@ -40,7 +40,10 @@ def _worker(rank, world, port, q):
     G = sh.state[1].copy(); G[:, 1:] += np.uint32(sh.lo)
     rows[:len(G)] = G
     full = D.stitch_graph(rows, len(X))
-    q.put((rank, ids, dists, el, full[:, 0].sum(), D.shard_range(len(X), rank, world)))
+    # HCNNG with the trees split over the ranks == the single-process build
+    Xh = X[:1500]
+    Gh = D.hcnng_build_tree_parallel(lambda t: o.hcnng_build(Xh, 1, 100, 3, seed=11 + t, threads=2), len(Xh), 5, 3)
+    q.put((rank, ids, dists, el, full[:, 0].sum(), D.shard_range(len(X), rank, world), Gh))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -74,6 +77,9 @@ def test_world2_sharded_search_timing_and_stitch(oracle):
         np.testing.assert_array_equal(res[r][2], exp_d)
         assert res[r][4] == degsum
     assert abs(res[0][3] - res[1][3]) < 1e-9 and res[0][3] >= 3 * 0.02      # both ranks report the slow rank's time
+    Gh = oracle.hcnng_build(X[:1500], 5, 100, 3, seed=11, threads=2)
+    for r in range(world):
+        np.testing.assert_array_equal(res[r][6], Gh)
     # the merged answer is a real top-k: close to brute force over the whole set
     gt, gd = oracle.bruteforce_knn(X, Q, 50)
     assert oracle.recall(exp_i, gt, gd, 10) > 0.9

@@ -79,6 +79,23 @@ def c5(n):
     print(json.dumps(out), flush=True)
 
 
+def c4shard(n):
+    """one of the 8 shards of C4 (synthetic 100M x 128 fp16): 12.5M points, own sub-graph, all 10K queries"""
+    t0 = time.time()
+    X = datasets.sift_like(n, 128, seed=1234, dtype=np.float16); Q = datasets.sift_like(10_000, 128, seed=4321, dtype=np.float16)
+    tg = time.time() - t0
+    ix = DeviceIndex(X, max_degree=64)
+    t0 = time.time(); st = ix.vamana_build(64, 128, 1.15, num_passes=2, seed=1); tb = time.time() - t0
+    gt, gd = ix.bruteforce_knn(Q, 100)
+    out = {"config": f"C4 one shard: {n}x128 fp16 Vamana R=64 L=128 a=1.15 x2, 10K queries", "datagen_s": tg, "build_s": tb,
+           "build_phases_s": {"search": st.t_search_s, "prune": st.t_prune_s, "bidirect": st.t_bidirect_s, "reprune": st.t_reprune_s}}
+    for beam in (32, 64, 128):
+        r, qps = search_stats(ix, Q, 10, beam)
+        out[f"beam{beam}"] = {"recall": recall_at_k(r["ids"], gt, gd, 10), "visited": float(r["visited_count"].mean()),
+                              "cmps": float(r["dist_cmps"].mean()), "qps_host_inclusive": qps}
+    print(json.dumps(out), flush=True)
+
+
 if __name__ == "__main__":
     for a in sys.argv[1:] or ["c1"]:
         name, _, arg = a.partition(":")
@@ -88,3 +105,5 @@ if __name__ == "__main__":
             c3(int(arg or 10_000_000))
         elif name == "c5":
             c5(int(arg or 1_000_000))
+        elif name == "c4shard":
+            c4shard(int(arg or 12_500_000))
