@@ -176,6 +176,7 @@ void beam_search(const Dataset& D, const void* q, int64_t self_id, const uint32_
 
   while (remain > offset && num_visited < QP.limit) {  // :107
     IdDist cur = unvisited[offset];
+    __builtin_prefetch(D.grow(cur.id));               // G[current.first].prefetch() (:110)
     visited.insert(std::upper_bound(visited.begin(), visited.end(), cur, less_id_dist), cur);
     R.visit_order.push_back(cur);
     num_visited++;
@@ -188,6 +189,9 @@ void beam_search(const Dataset& D, const void* q, int64_t self_id, const uint32_
     for (int64_t i = 0; i < ne; i++) {
       uint32_t a = row[1 + i];
       if (seen(a) || (int64_t)a == self_id) continue;  // :133 (filter is updated before same_as)
+      // Q_Points[a].prefetch() (:134; euclidian_point.h:129-133): one prefetch per 64-byte line of the row
+      for (uint64_t off = 0; off < (uint64_t)D.d * (D.dtype == DT_F32 ? 4 : D.dtype == DT_F16 ? 2 : 1); off += 64)
+        __builtin_prefetch((const char*)D.row(a) + off);
       keep.push_back(a);
     }
     dist_cmps += keep.size();  // :137 (and :155: one full distance per survivor)
