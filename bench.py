@@ -59,11 +59,11 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)   # RCCL; used only for barriers + max-over-ranks
 
-    # ---- synthetic SIFT-1M-shaped data: integer-valued in [0,255] (see datasets.sift_like) ----
+    # ---- synthetic SIFT-1M-shaped data: integer-valued in [0,255] (see datasets.sift1m_like: difficulty calibrated at n = 1M) ----
     t0 = time.time()
-    Xf = datasets.sift_like(args.n, args.d, seed=1234, dtype=np.float32)      # the reference's float points
+    Xf = datasets.sift1m_like(args.n, args.d, seed=1234, dtype=np.float32)    # the reference's float points
     X = Xf.astype(np.float16)                                                 # "fp32 -> fp16": exact here
-    Q = datasets.sift_like(args.nq, args.d, seed=4321 + rank, dtype=np.float16)
+    Q = datasets.sift1m_like(args.nq, args.d, seed=4321 + rank, dtype=np.float16)
     log(f"[rank {rank}] data generated in {time.time() - t0:.1f}s")
 
     # ---- index: replicated on every GPU, built on the device by the product's own builder ----
@@ -150,7 +150,7 @@ def main():
             "build_s": build_s,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "beam_search_kernel", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                         "kernel": "beam_search_b64_kernel" if args.beam <= 64 else "beam_search_kernel", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(ix, Xf, Q.astype(np.float32), args)

@@ -31,6 +31,16 @@ def sift_like(n, d=128, seed=1234, dtype=np.uint8, n_centers=256, rank=16):
     return x.astype(dtype)
 
 
+def sift1m_like(n, d=128, seed=1234, dtype=np.float16):
+    """The bench workload: integer-valued SIFT-shaped vectors whose difficulty is calibrated at n = 1M
+    (tools/calibrate_sift.py) so that Vamana R=64 L=128 gives recall@10 in
+    [0.95, 0.99] at beam 64 with SIFT-like work per query (~75 visited, ~3.4K distance comparisons);
+    `sift_like` (rank 16) is easier (recall 0.9997) and stays the generator of the unit tests."""
+    x = _mixture(n, d, seed, 256, 32, center_scale=22.0, basis_scale=9.0, noise_scale=14.0)
+    x = np.clip(np.rint(x + 100.0), 0, 255)
+    return x.astype(dtype)
+
+
 def deep_like(n, d=96, seed=1234, n_centers=256, rank=16):
     """Real-valued unit-norm float32 vectors (DEEP-shaped)."""
     x = _mixture(n, d, seed, n_centers, rank, center_scale=1.0, basis_scale=0.5, noise_scale=0.45)
