@@ -651,7 +651,6 @@ static Plan make_plan(const DeviceIndex& ix, const SearchArgs& a) {
                  (size_t)p.ccap * 2 + (nch1 ? 0 : (size_t)ix.nch * ix.lpc * 16);
   size_t hbytes = (size_t)4 << p.bits;
   p.hash_lds = (hbytes <= 16384) && (fixed + hbytes <= 64 * 1024);
-  if (getenv("PANN_EXP_GLOBAL_HASH") && hbytes > 4096) p.hash_lds = false;   // experiment switch
   p.lds_bytes = (uint32_t)(fixed + (p.hash_lds ? hbytes : 0));
   p.slots = 256 * 8;
   p.b64 = p.hash_lds && p.bcap == 64;
