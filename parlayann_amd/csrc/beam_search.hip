@@ -83,22 +83,10 @@ __device__ __forceinline__ void hstore(uint32_t* H, uint32_t s, uint32_t v) {
   if constexpr (HASH_LDS) H[s] = v;
   else __hip_atomic_store(H + s, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// Synchronisation of ONE wave with itself (its LDS / filter-table accesses become visible to its own
-// later accesses).  In a single-wave workgroup __syncthreads() compiles to exactly that (no s_barrier);
-// in the multi-wave kernel the leader wave must not use the workgroup barrier for it.
-template <int NW>
-__device__ __forceinline__ void lsync() {
-  if constexpr (NW == 1) {
-    __syncthreads();
-  } else {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-template <bool HASH_LDS, int NW = 1>
+template <bool HASH_LDS>
 __device__ __forceinline__ void hsync() {
   if constexpr (!HASH_LDS) __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): global table ops retire in order
-  lsync<NW>();
+  __syncthreads();
 }
 
 // first index in sorted A[0..n) with A[i] >= key
@@ -116,13 +104,13 @@ __device__ __forceinline__ uint32_t lower_bound_lds(const uint64_t* A, uint32_t 
 // lane i is a hit iff the LAST earlier lane with the same slot holds the same id, or, when there is
 // none, iff the table held a_i on entry.  Returns "seen" per lane and leaves the table as the
 // sequential loop would.
-template <bool HASH_LDS, int NW = 1>
+template <bool HASH_LDS>
 __device__ __forceinline__ bool filter_update(uint32_t* H, uint32_t hmask, bool active, uint32_t a, int lane) {
   const uint32_t s = (uint32_t)hash64_2((uint64_t)a) & hmask;
   uint32_t old = active ? hload<HASH_LDS>(H, s) : 0u;
-  hsync<HASH_LDS, NW>();
+  hsync<HASH_LDS>();
   if (active) hstore<HASH_LDS>(H, s, (uint32_t)lane);   // some lane of each slot group wins
-  hsync<HASH_LDS, NW>();
+  hsync<HASH_LDS>();
   uint32_t w = active ? hload<HASH_LDS>(H, s) : (uint32_t)lane;
   uint64_t losers = __ballot(active && w != (uint32_t)lane);
   int prev = -1;       // last earlier lane with my slot
@@ -140,9 +128,9 @@ __device__ __forceinline__ bool filter_update(uint32_t* H, uint32_t hmask, bool 
   }
   const uint32_t a_prev = __shfl(a, prev < 0 ? lane : prev);
   const bool seen = active && (prev >= 0 ? (a_prev == a) : (old == a));
-  hsync<HASH_LDS, NW>();
+  hsync<HASH_LDS>();
   if (active && last) hstore<HASH_LDS>(H, s, a);
-  hsync<HASH_LDS, NW>();
+  hsync<HASH_LDS>();
   return seen;
 }
 
@@ -170,46 +158,10 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
   return ((uint64_t)hi << 32) | lo;
 }
 
-// One wave's share of a cooperative gather (multi-wave kernel): candidates [wave*per, ...) of Pl;
-// survivors are appended to C at positions handed out by an LDS counter (the ORDER of C is irrelevant:
-// the merge ranks by key and equal keys are identical).
-template <int DT, int METRIC, int LPC, bool NCH1, int NW>
-__device__ __forceinline__ void gather_share(const BSParams& P, const QReg<DT>& qreg, const uint4* qlds, const uint32_t* Pl,
-                                             uint32_t m, uint32_t cutoff_ord, uint64_t* C, uint32_t* c_counter, int wave,
-                                             int lane) {
-  const uint32_t per = (m + NW - 1) / NW;
-  const uint32_t start = (uint32_t)wave * per;
-  if (start >= m) return;
-  const uint32_t cnt = min(per, m - start);
-  const PointsView PV{P.points, P.pstride, P.nch};
-  constexpr int SU = (16 * LPC) / PANN_WAVE > 0 ? (16 * LPC) / PANN_WAVE : 1;   // 16 candidates per batch and wave
-  gather_tile<DT, METRIC, LPC, NCH1, SU>(PV, qreg, qlds, Pl + start, cnt, lane,
-    [&](bool has, uint32_t, uint32_t id, float dist) {
-      const uint32_t ord = f2ord(dist);
-      const bool pass = has && (ord < cutoff_ord);
-      const uint64_t pm = __ballot(pass);
-      if (pm) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(c_counter, (uint32_t)__popcll(pm));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (pass) C[base + lanes_below(pm, lane)] = ((uint64_t)ord << 32) | id;
-      }
-    });
-}
-
 // Generic kernel: any beam (frontier in LDS), filter in LDS or in HBM scratch.
-// GU: candidate groups in flight per lane in the main gather.  Large beams are LDS-bound (16 KB filter at
-// beam 128 -> 8 queries per CU), so registers are free there and GU = 16 fetches a whole row's survivors
-// in one round trip.
-// NW: waves per query.  NW = 1: everything in one wave.  NW = 4 (large beams, where LDS caps the CU at ~8
-// queries and a lone wave per SIMD is bound by its own instruction issue): wave 0 runs the state machine,
-// waves 1..3 serve its gather requests -- each request splits one row's survivors four ways.
-template <int DT, int METRIC, int LPC, bool NCH1, bool HASH_LDS, int GU, int NW>
-__global__ void __launch_bounds__(PANN_WAVE * NW, PANN_MINWAVES) beam_search_kernel(BSParams P) {
-  static_assert(NW == 1 || HASH_LDS, "the multi-wave kernel keeps the filter in LDS");
-  const int lane = threadIdx.x & (PANN_WAVE - 1);
-  const int wave = threadIdx.x / PANN_WAVE;
-  (void)wave;
+template <int DT, int METRIC, int LPC, bool NCH1, bool HASH_LDS>
+__global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES) beam_search_kernel(BSParams P) {
+  const int lane = threadIdx.x;
   extern __shared__ __align__(16) uint8_t smem[];
   // ---- LDS carve (all regions 16 B aligned): 6.4 KB at beam 64 / degree 64 -> 24 queries per CU ----
   uint64_t* F = reinterpret_cast<uint64_t*>(smem);       // [bcap] frontier keys
@@ -221,8 +173,6 @@ __global__ void __launch_bounds__(PANN_WAVE * NW, PANN_MINWAVES) beam_search_ker
   uint16_t* CP = reinterpret_cast<uint16_t*>(NFv + P.bcap);  // [ccap] candidate's lower_bound in F
   uint4* qlds = reinterpret_cast<uint4*>(CP + P.ccap);   // [nch*LPC] query (generic variant)
   uint32_t* Hl = reinterpret_cast<uint32_t*>(qlds + (NCH1 ? 0 : P.nch * LPC));  // [1<<bits] if HASH_LDS
-  uint32_t* shm = Hl + (HASH_LDS ? (1u << P.bits) : 0u);   // [4] multi-wave mailbox: cmd, m, cutoff, candidate counter
-  enum { CMD_GATHER = 1, CMD_DONE = 2 };
 #define PANN_PL (reinterpret_cast<uint32_t*>(NF))        /* [64] filter survivors of one row chunk */
 
   const uint32_t hsize = 1u << P.bits, hmask = hsize - 1u;
@@ -238,26 +188,14 @@ __global__ void __launch_bounds__(PANN_WAVE * NW, PANN_MINWAVES) beam_search_ker
   while (qi < P.nq) {
     uint32_t* H = HASH_LDS ? Hl : P.hash_global + ((size_t)blockIdx.x << P.bits);
     // ---- filter init: hash_filter(1<<bits, -1) (:53) ----
-    for (uint32_t i = threadIdx.x; i < hsize; i += PANN_WAVE * NW) hstore<HASH_LDS>(H, i, SENTINEL);
+    for (uint32_t i = lane; i < hsize; i += PANN_WAVE) hstore<HASH_LDS>(H, i, SENTINEL);
 
     // ---- query vector -> registers (one chunk) or LDS (generic) ----
     const int64_t self = P.query_ids ? (int64_t)P.query_ids[qi] : -1;
     const uint8_t* qrow = P.query_ids ? P.points + (uint64_t)self * P.pstride : P.queries + (uint64_t)qi * P.qstride;
     QReg<DT> qreg{};
-    if (NW == 1 || NCH1 || wave == 0) load_query<DT, LPC, NCH1>(qrow, P.dbytes, P.nch, qreg, qlds, lane);
-    if constexpr (!HASH_LDS) __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();           // whole workgroup: filter initialised, query staged
-    if constexpr (NW > 1) {
-      if (wave != 0) {         // helper waves: serve gather requests until the leader is done
-        for (;;) {
-          __syncthreads();
-          const uint32_t cmd = shm[0];
-          if (cmd == CMD_DONE) return;
-          gather_share<DT, METRIC, LPC, NCH1, NW>(P, qreg, qlds, reinterpret_cast<const uint32_t*>(smem + shm[3]), shm[1], shm[2], C, shm + 4, wave, lane);
-          __syncthreads();
-        }
-      }
-    }
+    load_query<DT, LPC, NCH1>(qrow, P.dbytes, P.nch, qreg, qlds, lane);
+    hsync<HASH_LDS>();
 
     uint32_t f = 0;        // frontier size
     uint32_t c = 0;        // accumulated candidates
@@ -277,13 +215,13 @@ __global__ void __launch_bounds__(PANN_WAVE * NW, PANN_MINWAVES) beam_search_ker
       const uint32_t i = s0 + lane;
       const bool act = i < P.nstarts;
       const uint32_t a = act ? P.starts[(size_t)qi * P.starts_stride + i] : 0u;
-      (void)filter_update<HASH_LDS, NW>(H, hmask, act, a, lane);
+      (void)filter_update<HASH_LDS>(H, hmask, act, a, lane);
       if (act) PANN_PL[lane] = a;
-      lsync<NW>();
+      __syncthreads();
       const uint32_t m = min(P.nstarts - s0, (uint32_t)PANN_WAVE);
       // every start enters the frontier: cutoff above any finite distance
       c = gather_distances<DT, METRIC, LPC, NCH1, 4>(P, qreg, qlds, PANN_PL, m, 0xFFFFFFFFu, C, c, lane);
-      lsync<NW>();
+      __syncthreads();
     }
 
     bool first = true;  // the start-point pseudo-merge: no cut-prune, no visit
@@ -332,33 +270,20 @@ __global__ void __launch_bounds__(PANN_WAVE * NW, PANN_MINWAVES) beam_search_ker
           PANN_STAMP(1);   // adjacency row arrived
           if (am == 0ull) break;
           degsum += __popcll(am);
-          const bool seen = filter_update<HASH_LDS, NW>(H, hmask, act, a, lane);
+          const bool seen = filter_update<HASH_LDS>(H, hmask, act, a, lane);
           const bool keep = act && !seen && ((int64_t)a != self);     // :133
           const uint64_t km = __ballot(keep);
           const uint32_t m = __popcll(km);
           if (keep) PANN_PL[lanes_below(km, lane)] = a;
           dcmps += m;                                                 // :137,155
-          lsync<NW>();
+          __syncthreads();
           PANN_STAMP(2);   // filter + compaction
-          if (m) {
-            if constexpr (NW == 1) {
-              c = gather_distances<DT, METRIC, LPC, NCH1, GU>(P, qreg, qlds, PANN_PL, m, cutoff_ord, C, c, lane);
-            } else {   // split this row's survivors over the NW waves of the workgroup
-              if (lane == 0) {
-                shm[0] = CMD_GATHER; shm[1] = m; shm[2] = cutoff_ord;
-                shm[3] = (uint32_t)(reinterpret_cast<uint8_t*>(NF) - smem); shm[4] = c;
-              }
-              __syncthreads();
-              gather_share<DT, METRIC, LPC, NCH1, NW>(P, qreg, qlds, PANN_PL, m, cutoff_ord, C, shm + 4, 0, lane);
-              __syncthreads();
-              c = shm[4];
-            }
-          }
-          lsync<NW>();
+          if (m) c = gather_distances<DT, METRIC, LPC, NCH1, PANN_GU>(P, qreg, qlds, PANN_PL, m, cutoff_ord, C, c, lane);
+          __syncthreads();
           PANN_STAMP(3);   // gather + distances
         }
         // ---- skip the merge while too few candidates (:162-168) ----
-        lsync<NW>();
+        __syncthreads();
         const bool skip = (c == 0) || (P.skip_enabled && c < beam / 8 && more_unvisited);
         do_merge = !skip;
       }
@@ -378,11 +303,11 @@ __global__ void __launch_bounds__(PANN_WAVE * NW, PANN_MINWAVES) beam_search_ker
               dead |= (p < f && F[p] == key);
               if (dead) key = KEY_INF;
             }
-            lsync<NW>();       // all reads of C[0..j) by this chunk are done
+            __syncthreads();       // all reads of C[0..j) by this chunk are done
             if (j < c) { C[j] = key; CP[j] = (uint16_t)p; }
             // later chunks compare against earlier ORIGINAL keys; a killed earlier key was itself a
             // duplicate of a still earlier live one (or of F), so the verdict is unchanged.
-            lsync<NW>();
+            __syncthreads();
           }
           // A2: rank among live candidates -> direct placement into NF
           uint32_t nvalid = 0;
@@ -413,7 +338,7 @@ __global__ void __launch_bounds__(PANN_WAVE * NW, PANN_MINWAVES) beam_search_ker
               if (pos < beam) { NF[pos] = key; NFv[pos] = Fv[e]; }
             }
           }
-          lsync<NW>();
+          __syncthreads();
           const uint32_t f_old = f;
           uint32_t f_new = min(f_old + nvalid, beam);   // :185
           // ---- cut-prune (:190-195) ----
@@ -457,7 +382,7 @@ __global__ void __launch_bounds__(PANN_WAVE * NW, PANN_MINWAVES) beam_search_ker
           { uint64_t* t = F; F = NF; NF = t; uint8_t* tv = Fv; Fv = NFv; NFv = tv; }
           f = f_new;
           c = 0;                      // candidates.clear() (:182)
-          lsync<NW>();
+          __syncthreads();
         }
       }
       PANN_STAMP(4);     // merge (or nothing when skipped)
@@ -482,11 +407,7 @@ __global__ void __launch_bounds__(PANN_WAVE * NW, PANN_MINWAVES) beam_search_ker
       if (P.out.dist_cmps) P.out.dist_cmps[qi] = dcmps;
       if (P.out.degree_sum) P.out.degree_sum[qi] = degsum;
     }
-    lsync<NW>();
-    if constexpr (NW > 1) {
-      if (lane == 0) shm[0] = CMD_DONE;
-      __syncthreads();
-    }
+    __syncthreads();
     if constexpr (HASH_LDS) break;
     else {
       qi = 0;
@@ -712,7 +633,7 @@ static uint32_t filter_bits(int64_t beam) {  // :52
 }
 
 struct Plan {
-  uint32_t bits, bcap, ccap, deg_eff, dcap, lds_bytes; bool hash_lds; uint32_t slots; bool b64; bool mw;
+  uint32_t bits, bcap, ccap, deg_eff, dcap, lds_bytes; bool hash_lds; uint32_t slots; bool b64;
 };
 
 static Plan make_plan(const DeviceIndex& ix, const SearchArgs& a) {
@@ -730,10 +651,9 @@ static Plan make_plan(const DeviceIndex& ix, const SearchArgs& a) {
                  (size_t)p.ccap * 2 + (nch1 ? 0 : (size_t)ix.nch * ix.lpc * 16);
   size_t hbytes = (size_t)4 << p.bits;
   p.hash_lds = (hbytes <= 16384) && (fixed + hbytes <= 64 * 1024);
-  p.lds_bytes = (uint32_t)(fixed + (p.hash_lds ? hbytes : 0) + 32);   // + mailbox of the multi-wave variant
+  p.lds_bytes = (uint32_t)(fixed + (p.hash_lds ? hbytes : 0));
   p.slots = 256 * 8;
   p.b64 = p.hash_lds && p.bcap == 64;
-  p.mw = p.hash_lds && !p.b64 && p.lds_bytes >= 12 * 1024;   // <= 13 queries per CU: four waves per query
   if (p.b64) {   // register-frontier kernel: scratch[64] + candidates (exact, 8-entry granules) + flags + query + filter
     p.ccap = (std::max<uint32_t>(beam / 8 + p.deg_eff, a.nstarts) + 7) / 8 * 8;
     p.lds_bytes = (uint32_t)(64 * 8 + (size_t)p.ccap * 8 + 64 + (nch1 ? 0 : (size_t)ix.nch * ix.lpc * 16) + hbytes);
@@ -754,18 +674,13 @@ static hipError_t launch_variant(const BSParams& P, const Plan& p, hipStream_t s
   if (p.b64) {   // frontier in registers
     auto kern = beam_search_b64_kernel<DT, METRIC, LPC, NCH1>;
     hipLaunchKernelGGL(kern, dim3(P.nq), dim3(PANN_WAVE), p.lds_bytes, stream, P);
-  } else if (p.mw) {   // LDS-bound large beams: 4 waves per query
-    auto kern = beam_search_kernel<DT, METRIC, LPC, NCH1, true, 4, 4>;
-    if (p.lds_bytes > 48 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
-    hipLaunchKernelGGL(kern, dim3(P.nq), dim3(PANN_WAVE * 4), p.lds_bytes, stream, P);
   } else if (p.hash_lds) {
-    auto kern = beam_search_kernel<DT, METRIC, LPC, NCH1, true, 4, 1>;
+    auto kern = beam_search_kernel<DT, METRIC, LPC, NCH1, true>;
     if (p.lds_bytes > 48 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     hipLaunchKernelGGL(kern, dim3(P.nq), dim3(PANN_WAVE), p.lds_bytes, stream, P);
   } else {
-    auto kern = beam_search_kernel<DT, METRIC, LPC, NCH1, false, 4, 1>;
+    auto kern = beam_search_kernel<DT, METRIC, LPC, NCH1, false>;
     if (p.lds_bytes > 48 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     const uint32_t grid = (uint32_t)std::min<uint64_t>(P.nq, p.slots);
