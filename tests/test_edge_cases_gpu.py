@@ -1,0 +1,141 @@
+"""Edge cases of the hot path on the device vs. the oracle: empty and degenerate inputs, ties,
+duplicate adjacency entries (the reference sorts+uniques candidates "to be robust for neighbor lists
+with duplicates", beamSearch.h:171-175), tiny indices, extreme parameters."""
+import numpy as np
+import pytest
+
+from parlayann_amd import DeviceIndex, datasets
+
+pytestmark = pytest.mark.gpu
+
+
+def _cmp(o, g):
+    for f in ("ids", "dists", "frontier_size", "visited_count", "dist_cmps"):
+        np.testing.assert_array_equal(o[f], g[f], err_msg=f)
+
+
+def test_empty_batches_are_noops():
+    X = datasets.sift_like(100, 16, seed=1, dtype=np.uint8)
+    ix = DeviceIndex(X, max_degree=4)
+    r = ix.batch_search(np.zeros((0, 16), np.uint8), k=1, beam=4)
+    assert r["ids"].shape == (0, 1)
+    rows, dc = ix.robust_prune_batch(np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(1, np.uint64), 1.2, 4)
+    assert rows.shape == (0, 5)
+    ix.vamana_insert_batch(np.zeros(0, np.uint32), 4, 8, 1.2)
+    assert ix.pair_distances(np.zeros(0, np.uint32), np.zeros(0, np.uint32)).shape == (0,)
+    ix.close()
+
+
+def test_empty_graph_and_isolated_start(oracle):
+    X = datasets.sift_like(50, 16, seed=1, dtype=np.uint8)
+    Q = datasets.sift_like(5, 16, seed=2, dtype=np.uint8)
+    G = np.zeros((50, 9), np.uint32)
+    ix = DeviceIndex(X, G)
+    o = oracle.batch_search(X, G, queries=Q, k=1, beam=8, out_k=8)
+    g = ix.batch_search(Q, k=1, beam=8, out_k=8)
+    _cmp(o, g)
+    assert np.all(g["frontier_size"] == 1) and np.all(g["visited_count"] == 1)
+    ix.close()
+
+
+def test_single_point_and_tiny_indices(oracle):
+    for n in (1, 2, 3, 9):
+        X = datasets.sift_like(n, 8, seed=n, dtype=np.uint8)
+        G = np.zeros((n, 5), np.uint32)
+        for i in range(n):                      # ring
+            nb = [(i + 1) % n, (i + n - 1) % n] if n > 1 else []
+            nb = sorted(set(nb) - {i})
+            G[i, 0] = len(nb); G[i, 1:1 + len(nb)] = nb
+        ix = DeviceIndex(X, G)
+        Q = datasets.sift_like(4, 8, seed=77, dtype=np.uint8)
+        o = oracle.batch_search(X, G, queries=Q, k=1, beam=16, out_k=16)
+        g = ix.batch_search(Q, k=1, beam=16, out_k=16)
+        _cmp(o, g)
+        ix.close()
+
+
+def test_all_points_identical_ties_broken_by_id(oracle):
+    X = np.full((300, 32), 7, np.uint8)
+    G, _ = oracle.vamana_build(X, 8, 16, 1.2, seed=2)
+    ix = DeviceIndex(X, max_degree=8)
+    ix.vamana_build(8, 16, 1.2, seed=2)
+    np.testing.assert_array_equal(ix.get_graph()[:, 0], G[:, 0])
+    Q = np.full((3, 32), 9, np.uint8)
+    o = oracle.batch_search(X, G, queries=Q, k=5, beam=16, out_k=16)
+    ix2 = DeviceIndex(X, G)
+    g = ix2.batch_search(Q, k=5, beam=16, out_k=16)
+    _cmp(o, g)
+    f = g["frontier_size"][0]
+    assert np.all(np.diff(g["ids"][0, :f].astype(np.int64)) > 0)      # equal distances: ascending ids
+    li, ld = ix2.leaf_knn(np.arange(0, 300, 3, dtype=np.uint32), 10)
+    oi, od = oracle.leaf_knn(X, np.arange(0, 300, 3, dtype=np.uint32), 10)
+    np.testing.assert_array_equal(li, oi); np.testing.assert_array_equal(ld, od)
+    ix.close(); ix2.close()
+
+
+def test_duplicate_and_self_entries_in_adjacency_rows(oracle):
+    X = datasets.sift_like(2000, 32, seed=1, dtype=np.uint8)
+    Q = datasets.sift_like(60, 32, seed=2, dtype=np.uint8)
+    G, _ = oracle.vamana_build(X, 16, 32, 1.2, seed=3, max_degree=24)
+    rng = np.random.default_rng(0)
+    for v in rng.choice(2000, 400, replace=False):        # append duplicates of existing neighbours and self loops
+        d = int(G[v, 0])
+        extra = [G[v, 1 + rng.integers(0, d)], v, G[v, 1]][: 24 - d]
+        G[v, 1 + d:1 + d + len(extra)] = extra
+        G[v, 0] = d + len(extra)
+    ix = DeviceIndex(X, G)
+    for beam, k in ((32, 10), (64, 10), (100, 10)):
+        o = oracle.batch_search(X, G, queries=Q, k=k, beam=beam, out_k=beam, visited_cap=512)
+        g = ix.batch_search(Q, k=k, beam=beam, out_k=beam, visited_cap=512)
+        _cmp(o, g)
+    qids = rng.integers(0, 2000, 100).astype(np.uint32)    # build-mode search: self is skipped even when listed
+    o = oracle.batch_search(X, G, query_ids=qids, k=0, beam=48, cut=0.0, out_k=48)
+    g = ix.batch_search(query_ids=qids, k=0, beam=48, cut=0.0, out_k=48)
+    _cmp(o, g)
+    ix.close()
+
+
+def test_queries_that_are_base_points_and_extreme_params(oracle):
+    X = datasets.sift_like(3000, 64, seed=1, dtype=np.float16)
+    G, _ = oracle.vamana_build(X, 16, 32, 1.2, seed=3)
+    Q = X[::50].copy()
+    ix = DeviceIndex(X, G)
+    for kw in (dict(k=1, beam=1), dict(k=10, beam=10), dict(k=64, beam=64), dict(k=10, beam=64, limit=1),
+               dict(k=10, beam=64, cut=1.0), dict(k=10, beam=64, cut=1e9), dict(k=10, beam=64, degree_limit=0),
+               dict(k=10, beam=64, degree_limit=1), dict(k=3, beam=5, limit=3, degree_limit=2)):
+        kw.setdefault("cut", 1.35)
+        o = oracle.batch_search(X, G, queries=Q, out_k=kw["beam"], **kw)
+        g = ix.batch_search(Q, out_k=kw["beam"], **kw)
+        _cmp(o, g)
+    g = ix.batch_search(Q, k=1, beam=32)
+    assert np.mean(g["dists"][:, 0] == 0) > 0.7              # most queries find themselves at distance 0
+    ix.close()
+
+
+def test_robust_prune_degenerate_candidate_lists(oracle):
+    X = datasets.sift_like(500, 16, seed=1, dtype=np.uint8)
+    G, _ = oracle.vamana_build(X, 8, 16, 1.2, seed=3)
+    owners = np.array([0, 1, 2, 3, 4], np.uint32)
+    cands = [np.zeros(0, np.uint32), np.array([1, 1, 1], np.uint32), np.array([2], np.uint32),
+             np.arange(100, 140, dtype=np.uint32), np.array([4, 7, 7, 4, 9], np.uint32)]
+    off = np.concatenate([[0], np.cumsum([len(c) for c in cands])]).astype(np.uint64)
+    ix = DeviceIndex(X, G)
+    for add in (True, False):
+        for alpha in (1.0, 1.2, 100.0):
+            ro, dco = oracle.robust_prune_batch(X, G, owners, np.concatenate(cands), None, off, alpha, 8, add=add)
+            rg, dcg = ix.robust_prune_batch(owners, np.concatenate(cands), off, alpha, 8, add_out_nbrs=add)
+            np.testing.assert_array_equal(ro, rg); np.testing.assert_array_equal(dco, dcg)
+    ix.close()
+
+
+def test_zero_dimension_padding_and_odd_dims(oracle):
+    for d, dt in ((1, np.uint8), (3, np.float32), (5, np.float16), (63, np.int8), (65, np.uint8), (129, np.float16)):
+        X = datasets.sift_like(800, d, seed=d, dtype=np.float32)
+        X = (X - 128).clip(-127, 127).astype(np.int8) if dt == np.int8 else X.astype(dt)
+        G, _ = oracle.vamana_build(X, 8, 16, 1.2, seed=3)
+        ix = DeviceIndex(X, G)
+        Q = X[:20] if d < 3 else np.ascontiguousarray(X[5:45])
+        o = oracle.batch_search(X, G, queries=Q, k=5, beam=16, out_k=16)
+        g = ix.batch_search(Q, k=5, beam=16, out_k=16)
+        _cmp(o, g)
+        ix.close()
