@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--L", type=int, default=128)
     ap.add_argument("--alpha", type=float, default=1.15)
     ap.add_argument("--passes", type=int, default=2)
+    ap.add_argument("--dtype", default="f16", choices=["f16", "u8", "f32"],
+                    help="element type of the device copy (default f16 = BASELINE config[1]); the others are for comparison runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -62,8 +64,9 @@ def main():
     # ---- synthetic SIFT-1M-shaped data: integer-valued in [0,255] (see datasets.sift1m_like: difficulty calibrated at n = 1M) ----
     t0 = time.time()
     Xf = datasets.sift1m_like(args.n, args.d, seed=1234, dtype=np.float32)    # the reference's float points
-    X = Xf.astype(np.float16)                                                 # "fp32 -> fp16": exact here
-    Q = datasets.sift1m_like(args.nq, args.d, seed=4321 + rank, dtype=np.float16)
+    np_dt = {"f16": np.float16, "u8": np.uint8, "f32": np.float32}[args.dtype]
+    X = Xf.astype(np_dt)                                                      # "fp32 -> fp16": exact here (integer-valued)
+    Q = datasets.sift1m_like(args.nq, args.d, seed=4321 + rank, dtype=np_dt)
     log(f"[rank {rank}] data generated in {time.time() - t0:.1f}s")
 
     # ---- index: replicated on every GPU, built on the device by the product's own builder ----
@@ -77,7 +80,7 @@ def main():
 
     # ---- device-resident inputs / outputs ----
     lib = _capi.load()
-    d_q = torch.from_numpy(Q.view(np.int16)).to(dev)              # raw fp16 bits
+    d_q = torch.from_numpy(Q.view(np.uint8).reshape(args.nq, -1)).to(dev)   # raw bytes of the query rows
     d_starts = torch.zeros(1, dtype=torch.int32, device=dev)      # start point 0 (check_nn_recall.h:178)
     d_ids = torch.empty((args.nq, args.k), dtype=torch.int32, device=dev)
     d_dists = torch.empty((args.nq, args.k), dtype=torch.float32, device=dev)
@@ -91,7 +94,7 @@ def main():
     stream = torch.cuda.current_stream(dev)
 
     def step():
-        check(lib.pann_batch_search_dev(ix.handle, d_q.data_ptr(), None, args.nq, args.d * 2, d_starts.data_ptr(), 1,
+        check(lib.pann_batch_search_dev(ix.handle, d_q.data_ptr(), None, args.nq, args.d * Q.itemsize, d_starts.data_ptr(), 1,
                                         C.byref(qp), C.byref(out), C.c_void_p(stream.cuda_stream)))
 
     # ---- timed region: exactly --steps steps (barrier + synchronize on both sides, MAX over ranks:
@@ -117,7 +120,7 @@ def main():
     # ---- algorithmic bytes per launch from the reference's own counters ----
     vis = d_vis.cpu().numpy().astype(np.int64); cmps = d_cmps.cpu().numpy().astype(np.int64)
     deg = d_deg.cpu().numpy().astype(np.int64)
-    esize = 2
+    esize = Q.itemsize
     bytes_q = cmps * args.d * esize + (vis + deg) * 4 + args.d * esize + args.k * 8
     alg_bytes = int(bytes_q.sum())
     achieved = alg_bytes / (kern_ms / 1e3) / 1e9
@@ -139,8 +142,8 @@ def main():
             "metric": "QPS @ recall@10>=0.95, SIFT-1M d=128 beam=64; achieved HBM GB/s vs roofline",
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"SIFT-1M-shaped batched beam search: {args.n}x{args.d} integer-valued fp32->fp16 base, "
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"SIFT-1M-shaped batched beam search: {args.n}x{args.d} integer-valued fp32->{args.dtype} base, "
                                    f"{args.nq} queries/step/GPU, beam={args.beam} k={args.k} cut=1.35 start=0, prebuilt "
                                    f"Vamana R={args.R} L={args.L} alpha={args.alpha} x{args.passes} passes (built on device)",
                        "n": args.n, "d": args.d, "nq_per_gpu": args.nq, "beam": args.beam, "k": args.k,
