@@ -208,6 +208,15 @@ int pann_leaf_knn_batch(pann_index* idx, const uint32_t* ids, const uint64_t* le
 int pann_pivot_split(pann_index* idx, const uint32_t* ids, const uint64_t* seg_offsets, uint64_t nseg,
                      const uint32_t* pivot_a, const uint32_t* pivot_b, uint8_t* out_side);
 
+/* Whole HCNNG build_index (hcnng_index.h:273-281) on the device: for each of num_clusters trees the
+ * random two-pivot cluster tree (clusterEdge.h:99-144; level-synchronous: split kernel, prefix scan,
+ * stable scatter), the all-pairs 10-NN of every leaf (hcnng_index.h:145-181), the per-leaf
+ * de-duplicated, degree-bounded Kruskal (:183-228) and process_edges (:117-131).  Edges are appended to
+ * the handle's graph (max_deg must be >= num_clusters * mst_deg, types.h:210-214).  Seeding rules as in
+ * DESIGN.md "Build determinism".  times3 (optional): seconds spent in {tree, leaf kNN, MST}. */
+int pann_hcnng_build(pann_index* idx, uint32_t num_clusters, uint32_t cluster_size, uint32_t mst_deg,
+                     uint64_t seed, double* times3);
+
 /* Brute-force k nearest base points for nq external queries (compute_groundtruth.cpp:22-59):
  * out rows sorted by (dist,id). Host pointers. */
 int pann_bruteforce_knn(pann_index* idx, const void* queries, uint64_t nq, uint64_t q_stride_bytes,

@@ -83,6 +83,7 @@ SIGNATURES = {
     "pann_rerank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p,
                               C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
     "pann_pivot_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pann_hcnng_build": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p]),
     "pann_bruteforce_knn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p,
                                       C.c_void_p]),
 }

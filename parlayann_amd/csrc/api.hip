@@ -668,4 +668,13 @@ int pann_rerank(pann_index* idx, const void* queries, uint64_t nq, uint64_t q_st
   return PANN_OK;
 }
 
+
+int pann_hcnng_build(pann_index* idx, uint32_t num_clusters, uint32_t cluster_size, uint32_t mst_deg, uint64_t seed,
+                     double* times3) {
+  if (int rc = check_idx(idx, "pann_hcnng_build")) return rc;
+  if (num_clusters == 0 || mst_deg == 0) { set_error("pann_hcnng_build: num_clusters and mst_deg must be positive"); return PANN_ERR_BAD_ARG; }
+  DeviceGuard g(idx->device);
+  return hcnng_build_dev(idx->ix, idx->ws2, idx->stream, num_clusters, cluster_size, mst_deg, seed, times3);
+}
+
 }  // extern "C"

@@ -1,0 +1,389 @@
+// hcnng_build.hip -- HCNNG index construction on gfx950.
+//
+//   cluster::random_clustering   HCNNG/clusterEdge.h:99-144   -> level-synchronous tree: pivots chosen on the host
+//        (a few thousand clusters per level), tree_split_kernel (two-pivot distance test, :71-83),
+//        rocprim exclusive scan, tree_scatter_kernel (parlay::filter keeps order -> stable partition)
+//   hcnng_index::MSTk            HCNNG/hcnng_index.h:134-229  -> dense_topk (dense.hip) for the 10-NN of every
+//        leaf, leaf_edges_kernel + rocprim segmented sort (less_dup order :183-201), leaf_mst_kernel
+//        (unique, degree-bounded Kruskal with the reference's DisjointSet :36-89, process_edges :117-131)
+//
+// The sequential part of Kruskal runs on lane 0 of one wave per leaf (union-find arrays in LDS for
+// leaves up to 4096 members, in HBM scratch beyond); thousands of leaves run concurrently.
+#include <chrono>
+#include <cstring>
+#include <vector>
+
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
+
+#include "pann_device.h"
+
+namespace pann {
+
+__device__ __forceinline__ uint64_t hc_mix(uint64_t x) {
+  x += 0x9e3779b97f4a7c15ull;
+  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+  x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+  return x ^ (x >> 31);
+}
+static inline uint64_t hc_mix_host(uint64_t x) {
+  x += 0x9e3779b97f4a7c15ull;
+  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+  x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+  return x ^ (x >> 31);
+}
+
+struct SplitCluster { uint32_t lo, len, pa, pb; };   // pa/pb: POSITIONS of the two pivots in the ids array
+
+// side[pos] = 0 when d(ids[pos], pivot_a) <= d(ids[pos], pivot_b)   (clusterEdge.h:71-83); also flags
+// clusters whose two pivot vectors are identical (:107)
+template <int DT, int METRIC, int LPC, bool NCH1>
+__global__ void __launch_bounds__(PANN_WAVE) tree_split_kernel(PointsView pv, uint32_t dbytes, const uint32_t* ids,
+                                                               const SplitCluster* cl, const uint32_t* tile_cl,
+                                                               const uint32_t* tile_off, uint32_t* is_first,
+                                                               uint32_t* same_flag) {
+  const int lane = threadIdx.x;
+  __shared__ uint32_t Pl[PANN_WAVE];
+  __shared__ float Da[PANN_WAVE];
+  extern __shared__ __align__(16) uint8_t smem[];
+  uint4* qlds = reinterpret_cast<uint4*>(smem);
+  const uint32_t t = blockIdx.x;
+  const SplitCluster c = cl[tile_cl[t]];
+  const uint32_t off = tile_off[t];
+  const uint32_t mm = min(c.len - off, (uint32_t)PANN_WAVE);
+  const uint32_t ida = ids[c.pa], idb = ids[c.pb];
+  if (lane < (int)mm) Pl[lane] = ids[c.lo + off + lane];
+  if (off == 0) {   // first tile of the cluster: are the two pivot vectors identical?
+    const uint8_t* ra = pv.points + (uint64_t)ida * pv.pstride;
+    const uint8_t* rb = pv.points + (uint64_t)idb * pv.pstride;
+    bool diff = false;
+    for (uint32_t b = lane * 16; b < pv.pstride; b += PANN_WAVE * 16) {
+      const uint4 x = *reinterpret_cast<const uint4*>(ra + b), y = *reinterpret_cast<const uint4*>(rb + b);
+      diff |= (x.x != y.x) | (x.y != y.y) | (x.z != y.z) | (x.w != y.w);
+    }
+    const uint64_t dm = __ballot(diff);
+    if (lane == 0) same_flag[tile_cl[t]] = dm ? 0u : 1u;
+  }
+  QReg<DT> qreg{};
+  load_query<DT, LPC, NCH1>(pv.points + (uint64_t)ida * pv.pstride, pv.pstride, pv.nch, qreg, qlds, lane);
+  __syncthreads();
+  gather_tile<DT, METRIC, LPC, NCH1, 4>(pv, qreg, qlds, Pl, mm, lane,
+    [&](bool has, uint32_t ci, uint32_t, float dist) { if (has) Da[ci] = dist; });
+  __syncthreads();
+  load_query<DT, LPC, NCH1>(pv.points + (uint64_t)idb * pv.pstride, pv.pstride, pv.nch, qreg, qlds, lane);
+  __syncthreads();
+  gather_tile<DT, METRIC, LPC, NCH1, 4>(pv, qreg, qlds, Pl, mm, lane,
+    [&](bool has, uint32_t ci, uint32_t, float dist) { if (has) is_first[c.lo + off + ci] = (Da[ci] <= dist) ? 1u : 0u; });
+  (void)dbytes;
+}
+
+__global__ void cluster_counts_kernel(const uint32_t* scan0, const SplitCluster* cl, uint32_t ncl, uint32_t* n0_out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ncl) n0_out[i] = scan0[cl[i].lo + cl[i].len] - scan0[cl[i].lo];
+}
+
+struct ScatterCluster { uint32_t lo, len, n0, half; };
+// stable partition of every splitting cluster: first-side members keep their order at [lo, lo+n0),
+// the others at [lo+n0, lo+len); "halved" clusters (:108-115) and finished clusters do not move
+__global__ void tree_scatter_kernel(const uint32_t* ids, uint32_t* newids, const uint32_t* is_first, const uint32_t* scan0,
+                                    const ScatterCluster* cl, const uint32_t* tile_cl, const uint32_t* tile_off) {
+  const uint32_t t = blockIdx.x;
+  const ScatterCluster c = cl[tile_cl[t]];
+  const uint32_t i = tile_off[t] + threadIdx.x;
+  if (i >= c.len) return;
+  const uint32_t pos = c.lo + i;
+  uint32_t np = pos;
+  if (!c.half) {
+    const uint32_t r0 = scan0[pos] - scan0[c.lo];         // first-side members before me in my cluster
+    np = is_first[pos] ? c.lo + r0 : c.lo + c.n0 + (i - r0);
+  }
+  newids[np] = ids[pos];
+}
+
+__global__ void fill_u32(uint32_t* p, uint64_t n, uint32_t v) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void iota_u32(uint32_t* p, uint64_t n) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (i < n) p[i] = (uint32_t)i;
+}
+__global__ void invert_perm(const uint32_t* ids, uint32_t* pos, uint64_t n) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (i < n) pos[ids[i]] = (uint32_t)i;
+}
+__global__ void degree_init_kernel(const uint32_t* graph, uint32_t gstride, uint32_t* deg, uint64_t n) {
+  const uint64_t v = blockIdx.x;
+  if (v >= n) return;
+  const uint32_t* row = graph + v * gstride;
+  uint32_t d = 0;
+  for (uint32_t i0 = 0; i0 < gstride; i0 += 64) {
+    const uint32_t i = i0 + threadIdx.x;
+    d += __popcll(__ballot(i < gstride && row[i] != SENTINEL));
+  }
+  if (threadIdx.x == 0) deg[v] = d;
+}
+
+// edge keys of one leaf member: (ord(dist) << 32) | (min(i,j) << 16) | max(i,j), local indices (:160-170)
+__global__ void leaf_edges_kernel(const uint32_t* nn_ids, const float* nn_d, const uint32_t* pos, const uint32_t* leaf_lo_of,
+                                  uint32_t m, uint64_t total, uint64_t* keys) {
+  const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (t >= total * m) return;
+  const uint64_t p = t / m;                    // position of the member in the ids array
+  const uint32_t nb = nn_ids[t];
+  uint64_t key = KEY_INF;
+  if (nb != SENTINEL) {
+    const uint32_t lo = leaf_lo_of[p];
+    const uint32_t i = (uint32_t)(p - lo), j = pos[nb] - lo;
+    key = ((uint64_t)f2ord(nn_d[t]) << 32) | ((uint64_t)min(i, j) << 16) | max(i, j);
+  }
+  keys[t] = key;
+}
+__global__ void leaf_lo_kernel(const uint64_t* leaf_off, uint32_t nleaves, uint32_t* leaf_lo_of) {
+  const uint32_t l = blockIdx.x;
+  if (l >= nleaves) return;
+  for (uint64_t p = leaf_off[l] + threadIdx.x; p < leaf_off[l + 1]; p += blockDim.x) leaf_lo_of[p] = (uint32_t)leaf_off[l];
+}
+
+struct MstArgs {
+  const uint64_t* keys;            // sorted per leaf: [leaf_off[l]*m, leaf_off[l+1]*m)
+  const uint64_t* leaf_off; uint32_t nleaves; uint32_t m;
+  const uint32_t* ids;             // position -> vertex id
+  uint32_t* graph; uint32_t gstride; uint32_t max_deg; uint32_t* deg;
+  uint32_t mst_deg;
+  int32_t* g_parent; uint8_t* g_rank; uint8_t* g_degree;    // HBM scratch indexed by position (large leaves)
+};
+
+// modified Kruskal of one leaf (hcnng_index.h:202-228) + process_edges (:117-131)
+__global__ void __launch_bounds__(PANN_WAVE) leaf_mst_kernel(MstArgs A) {
+  const int lane = threadIdx.x;
+  const uint32_t l = blockIdx.x;
+  extern __shared__ __align__(16) uint8_t smem[];
+  const uint64_t lo = A.leaf_off[l];
+  const uint32_t N = (uint32_t)(A.leaf_off[l + 1] - lo);
+  if (N < 2) return;
+  const bool in_lds = N <= 4096;
+  int32_t* parent = in_lds ? reinterpret_cast<int32_t*>(smem) : A.g_parent + lo;
+  uint8_t* rnk = in_lds ? reinterpret_cast<uint8_t*>(smem + 4096 * 4) : A.g_rank + lo;
+  uint8_t* dgr = in_lds ? reinterpret_cast<uint8_t*>(smem + 4096 * 5) : A.g_degree + lo;
+  if (in_lds) { for (uint32_t i = lane; i < N; i += PANN_WAVE) { parent[i] = (int32_t)i; rnk[i] = 0; dgr[i] = 0; } }
+  else {
+    for (uint32_t i = lane; i < N; i += PANN_WAVE) {
+      __hip_atomic_store(parent + i, (int32_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(rnk + i, (uint8_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(dgr + i, (uint8_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+  }
+  __threadfence_block();
+  __syncthreads();
+  const uint64_t* K = A.keys + lo * A.m;
+  const uint64_t ne = (uint64_t)N * A.m;
+  // accessors: LDS for leaves up to 4096 members; HBM scratch (L1-bypassing loads/stores) beyond
+  auto ldp = [&](int i) -> int { return in_lds ? parent[i] : __hip_atomic_load(parent + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto stp = [&](int i, int v) { if (in_lds) parent[i] = v; else __hip_atomic_store(parent + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto ld8 = [&](uint8_t* a, int i) -> uint8_t { return in_lds ? a[i] : __hip_atomic_load(a + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto st8 = [&](uint8_t* a, int i, uint8_t v) { if (in_lds) a[i] = v; else __hip_atomic_store(a + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto find = [&](int x) { for (;;) { const int px = ldp(x); if (px == x) return x; const int gp = ldp(px); stp(x, gp); x = gp; } };
+  auto root_ro = [&](int x) { for (;;) { const int px = ldp(x); if (px == x) return x; x = px; } };
+  uint64_t prev = KEY_INF;
+  uint64_t e_unique = 0;      // index in the de-duplicated sequence (remove_duplicates_ordered :202-203)
+  for (uint64_t e = 0; e < ne; e++) {
+    const uint64_t key = K[e];            // uniform address: one broadcast load
+    if (key == KEY_INF) break;            // padding sorts last
+    if (key == prev) continue;
+    prev = key;
+    const int a = (int)((key >> 16) & 0xFFFF), b = (int)(key & 0xFFFF);
+    if (lane == 0) {
+      const int ra = find(a), rb = find(b);
+      const uint8_t da = ld8(dgr, a), db = ld8(dgr, b);
+      if (ra != rb && da < A.mst_deg && db < A.mst_deg) {
+        const uint32_t va = A.ids[lo + a], vb = A.ids[lo + b];
+        // MST_edges gets (a,b) then (b,a); process_edges appends while the row has room.  A vertex sits in
+        // exactly one leaf per tree, so its row position is (degree before this tree) + (edges of this leaf).
+        const uint32_t pa = A.deg[va] + da, pb = A.deg[vb] + db;
+        if (pa < A.max_deg) A.graph[(size_t)va * A.gstride + pa] = vb;
+        if (pb < A.max_deg) A.graph[(size_t)vb * A.gstride + pb] = va;
+        st8(dgr, a, da + 1); st8(dgr, b, db + 1);
+        const uint8_t ka = ld8(rnk, a), kb = ld8(rnk, b);     // the reference reads rank[x], not rank[root] (:53-54)
+        if (ka < kb) stp(ra, rb); else { stp(rb, ra); if (ka == kb) st8(rnk, ra, ld8(rnk, ra) + 1); }
+      }
+    }
+    // :221-225  every N processed edges: stop when everything is in one set
+    if (e_unique % N == 0) {
+      __threadfence_block();
+      __syncthreads();
+      const int r0 = root_ro(0);
+      bool all = true;
+      for (uint32_t i = lane; i < N; i += PANN_WAVE) all &= (root_ro((int)i) == r0);
+      const bool full = __ballot(!all) == 0ull;
+      __syncthreads();
+      if (full) break;
+    }
+    e_unique++;
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (uint32_t i = lane; i < N; i += PANN_WAVE) {          // commit the rows' new degrees (capped like the appends)
+    const uint32_t v = A.ids[lo + i];
+    A.deg[v] = min(A.deg[v] + (uint32_t)ld8(dgr, (int)i), A.max_deg);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+
+int dense_topk_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, const uint8_t* d_a_ext, uint64_t a_stride,
+                   const uint32_t* d_a_ids, const uint32_t* d_b_ids, const uint64_t* d_a_off, const uint64_t* d_b_off,
+                   const uint32_t* d_tile_seg, const uint32_t* d_tile_a0, uint32_t ntiles, uint64_t na, uint64_t nb,
+                   uint32_t nsplit, uint32_t m, int exclude_same, uint32_t* d_out_ids, float* d_out_dists);
+
+struct HBuf {   // small RAII device buffer
+  void* p = nullptr;
+  ~HBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess ? 0 : 1; }
+  template <typename T> T* as() { return (T*)p; }
+};
+
+int hcnng_build_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, uint32_t num_clusters, uint32_t cluster_size,
+                    uint32_t mst_deg, uint64_t seed, double* times3) {
+  const uint64_t n = ix.n;
+  const uint32_t m = 10;                                  // hcnng_index.h:140
+  if (cluster_size < 2 || cluster_size > 65535) { set_error("pann_hcnng_build: cluster_size must be in [2,65535]"); return PANN_ERR_BAD_ARG; }
+  if ((uint64_t)num_clusters * mst_deg > ix.max_deg) { set_error("pann_hcnng_build: max_deg < num_clusters * mst_deg"); return PANN_ERR_BAD_ARG; }
+  if (mst_deg > 255) { set_error("pann_hcnng_build: mst_deg > 255"); return PANN_ERR_BAD_ARG; }
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto secs = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
+  const PointsView pv{ix.points, ix.pstride, ix.nch};
+  const size_t qb = ix.nch == 1 ? 0 : (size_t)ix.nch * ix.lpc * 16;
+  const uint32_t nb256 = (uint32_t)((n + 255) / 256);
+
+  HBuf b_ids, b_new, b_first, b_scan, b_pos, b_deg, b_leaflo, b_nnids, b_nnd, b_ka, b_kb, b_par, b_rnk, b_dgr, b_tmp;
+  size_t scan_tmp = 0, sort_tmp = 0;
+  (void)rocprim::exclusive_scan(nullptr, scan_tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st);
+  (void)rocprim::segmented_radix_sort_keys(nullptr, sort_tmp, (uint64_t*)nullptr, (uint64_t*)nullptr, (unsigned)(n * m), (unsigned)(n / 2 + 2),
+                                           (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0, 64, st);
+  if (n * m >= 0xFFFFFFF0ull) { set_error("pann_hcnng_build: n too large for 32-bit edge offsets"); return PANN_ERR_BAD_ARG; }
+  if (b_ids.alloc(n * 4) || b_new.alloc(n * 4) || b_first.alloc((n + 1) * 4) || b_scan.alloc((n + 1) * 4) || b_pos.alloc(n * 4) ||
+      b_deg.alloc(n * 4) || b_leaflo.alloc(n * 4) || b_nnids.alloc(n * m * 4) || b_nnd.alloc(n * m * 4) || b_ka.alloc(n * m * 8) ||
+      b_kb.alloc(n * m * 8) || b_par.alloc(n * 4) || b_rnk.alloc(n) || b_dgr.alloc(n) || b_tmp.alloc(std::max(scan_tmp, sort_tmp) + 256)) {
+    set_error("pann_hcnng_build: hipMalloc failed"); return PANN_ERR_HIP;
+  }
+  hipLaunchKernelGGL(degree_init_kernel, dim3((uint32_t)n), dim3(64), 0, st, ix.graph, ix.gstride, b_deg.as<uint32_t>(), n);
+  PANN_HIP(hipGetLastError());
+
+  struct Cl { uint32_t lo, len; uint64_t rnd; };
+  double t_tree = 0, t_leaf = 0, t_mst = 0;
+  for (uint32_t t = 0; t < num_clusters; t++) {
+    const auto t0 = now();
+    uint32_t* ids = b_ids.as<uint32_t>();
+    uint32_t* newids = b_new.as<uint32_t>();
+    hipLaunchKernelGGL(iota_u32, dim3(nb256), dim3(256), 0, st, ids, n);
+    std::vector<Cl> level = {Cl{0, (uint32_t)n, hc_mix_host(hc_mix_host(seed + t))}};
+    std::vector<uint64_t> leaf_off;                       // leaf start positions (sorted at the end)
+    while (!level.empty()) {
+      std::vector<SplitCluster> sc; std::vector<Cl> src;
+      for (const Cl& c : level) {
+        if (c.len <= cluster_size) { leaf_off.push_back(c.lo); continue; }            // clusterEdge.h:103-104
+        const uint64_t fi = hc_mix_host(c.rnd + 0) % c.len;                            // select_two_random :40-50
+        const uint64_t su = hc_mix_host(c.rnd + 1) % (c.len - 1);
+        const uint64_t si = su < fi ? su : su + 1;
+        sc.push_back(SplitCluster{c.lo, c.len, (uint32_t)(c.lo + fi), (uint32_t)(c.lo + si)});
+        src.push_back(c);
+      }
+      if (sc.empty()) break;
+      std::vector<uint32_t> tile_cl, tile_off;
+      for (size_t ci = 0; ci < sc.size(); ci++)
+        for (uint32_t o = 0; o < sc[ci].len; o += 64) { tile_cl.push_back((uint32_t)ci); tile_off.push_back(o); }
+      const size_t nt = tile_cl.size(), ncl = sc.size();
+      HBuf d_sc, d_tcl, d_toff, d_same, d_scat;
+      if (d_sc.alloc(ncl * sizeof(SplitCluster)) || d_tcl.alloc(nt * 4) || d_toff.alloc(nt * 4) || d_same.alloc(ncl * 4) ||
+          d_scat.alloc(ncl * sizeof(ScatterCluster))) { set_error("pann_hcnng_build: hipMalloc failed"); return PANN_ERR_HIP; }
+      PANN_HIP(hipMemcpyAsync(d_sc.p, sc.data(), ncl * sizeof(SplitCluster), hipMemcpyHostToDevice, st));
+      PANN_HIP(hipMemcpyAsync(d_tcl.p, tile_cl.data(), nt * 4, hipMemcpyHostToDevice, st));
+      PANN_HIP(hipMemcpyAsync(d_toff.p, tile_off.data(), nt * 4, hipMemcpyHostToDevice, st));
+      PANN_HIP(hipMemsetAsync(b_first.p, 0, (n + 1) * 4, st));
+#define CALL_TS(DT, MT, L, N1) hipLaunchKernelGGL((tree_split_kernel<DT, MT, L, N1>), dim3((uint32_t)nt), dim3(PANN_WAVE), qb, st, pv, ix.dbytes, ids, d_sc.as<SplitCluster>(), d_tcl.as<uint32_t>(), d_toff.as<uint32_t>(), b_first.as<uint32_t>(), d_same.as<uint32_t>())
+      PANN_TYPE_SWITCH(ix, CALL_TS);
+#undef CALL_TS
+      PANN_HIP(hipGetLastError());
+      size_t tb = scan_tmp;
+      PANN_HIP(rocprim::exclusive_scan(b_tmp.p, tb, b_first.as<uint32_t>(), b_scan.as<uint32_t>(), 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st));
+      // per-cluster first-side counts and identical-pivot flags back to the host (a few KB)
+      std::vector<uint32_t> h_same(ncl), h_n0(ncl);
+      HBuf d_n0;
+      if (d_n0.alloc(ncl * 4)) { set_error("pann_hcnng_build: hipMalloc failed"); return PANN_ERR_HIP; }
+      hipLaunchKernelGGL(cluster_counts_kernel, dim3((uint32_t)((ncl + 255) / 256)), dim3(256), 0, st, b_scan.as<uint32_t>(),
+                         d_sc.as<SplitCluster>(), (uint32_t)ncl, d_n0.as<uint32_t>());
+      PANN_HIP(hipMemcpyAsync(h_same.data(), d_same.p, ncl * 4, hipMemcpyDeviceToHost, st));
+      PANN_HIP(hipMemcpyAsync(h_n0.data(), d_n0.p, ncl * 4, hipMemcpyDeviceToHost, st));
+      PANN_HIP(hipStreamSynchronize(st));
+      std::vector<ScatterCluster> scat(ncl);
+      std::vector<Cl> next;
+      next.reserve(2 * ncl);
+      for (size_t ci = 0; ci < ncl; ci++) {
+        uint32_t n0 = h_n0[ci];
+        const bool half = h_same[ci] || n0 == 0 || n0 == sc[ci].len;                  // :107-115 (+ empty-side guard)
+        if (half) n0 = sc[ci].len / 2;
+        scat[ci] = ScatterCluster{sc[ci].lo, sc[ci].len, n0, half ? 1u : 0u};
+        const uint64_t r = src[ci].rnd;
+        next.push_back(Cl{sc[ci].lo, n0, hc_mix_host(hc_mix_host(r) + 0 + 17)});     // rnd.fork(0) :85
+        next.push_back(Cl{sc[ci].lo + n0, sc[ci].len - n0, hc_mix_host(hc_mix_host(r) + 1 + 17)});
+      }
+      PANN_HIP(hipMemcpyAsync(d_scat.p, scat.data(), ncl * sizeof(ScatterCluster), hipMemcpyHostToDevice, st));
+      PANN_HIP(hipMemcpyAsync(newids, ids, n * 4, hipMemcpyDeviceToDevice, st));      // finished clusters keep their place
+      hipLaunchKernelGGL(tree_scatter_kernel, dim3((uint32_t)nt), dim3(64), 0, st, ids, newids, b_first.as<uint32_t>(),
+                         b_scan.as<uint32_t>(), d_scat.as<ScatterCluster>(), d_tcl.as<uint32_t>(), d_toff.as<uint32_t>());
+      PANN_HIP(hipGetLastError());
+      PANN_HIP(hipStreamSynchronize(st));   // the per-level buffers go out of scope
+      std::swap(ids, newids);
+      level.swap(next);
+    }
+    std::sort(leaf_off.begin(), leaf_off.end());
+    leaf_off.push_back(n);
+    const uint32_t nleaves = (uint32_t)leaf_off.size() - 1;
+    const auto t1 = now();
+
+    // ---- all-pairs 10-NN of every leaf (device ids, no host copy) ----
+    std::vector<uint32_t> tseg, ta0;
+    for (uint32_t l = 0; l < nleaves; l++)
+      for (uint64_t a = leaf_off[l]; a < leaf_off[l + 1]; a += 64) { tseg.push_back(l); ta0.push_back((uint32_t)a); }
+    HBuf d_loff, d_tseg, d_ta0, d_seg_b, d_seg_e;
+    if (d_loff.alloc((nleaves + 1) * 8) || d_tseg.alloc(tseg.size() * 4) || d_ta0.alloc(ta0.size() * 4) || d_seg_b.alloc(nleaves * 4) ||
+        d_seg_e.alloc(nleaves * 4)) { set_error("pann_hcnng_build: hipMalloc failed"); return PANN_ERR_HIP; }
+    PANN_HIP(hipMemcpyAsync(d_loff.p, leaf_off.data(), (nleaves + 1) * 8, hipMemcpyHostToDevice, st));
+    PANN_HIP(hipMemcpyAsync(d_tseg.p, tseg.data(), tseg.size() * 4, hipMemcpyHostToDevice, st));
+    PANN_HIP(hipMemcpyAsync(d_ta0.p, ta0.data(), ta0.size() * 4, hipMemcpyHostToDevice, st));
+    if (int rc = dense_topk_dev(ix, ws, st, nullptr, 0, ids, ids, d_loff.as<uint64_t>(), d_loff.as<uint64_t>(), d_tseg.as<uint32_t>(),
+                                d_ta0.as<uint32_t>(), (uint32_t)tseg.size(), n, n, 1, m, 1, b_nnids.as<uint32_t>(), b_nnd.as<float>())) return rc;
+    PANN_HIP(hipStreamSynchronize(st));
+    const auto t2 = now();
+
+    // ---- edges, per-leaf sort (less_dup order), Kruskal, process_edges ----
+    hipLaunchKernelGGL(invert_perm, dim3(nb256), dim3(256), 0, st, ids, b_pos.as<uint32_t>(), n);
+    hipLaunchKernelGGL(leaf_lo_kernel, dim3(nleaves), dim3(64), 0, st, d_loff.as<uint64_t>(), nleaves, b_leaflo.as<uint32_t>());
+    const uint64_t ne = n * m;
+    hipLaunchKernelGGL(leaf_edges_kernel, dim3((uint32_t)((ne + 255) / 256)), dim3(256), 0, st, b_nnids.as<uint32_t>(), b_nnd.as<float>(),
+                       b_pos.as<uint32_t>(), b_leaflo.as<uint32_t>(), m, n, b_ka.as<uint64_t>());
+    PANN_HIP(hipGetLastError());
+    std::vector<uint32_t> seg_b(nleaves), seg_e(nleaves);
+    for (uint32_t l = 0; l < nleaves; l++) { seg_b[l] = (uint32_t)(leaf_off[l] * m); seg_e[l] = (uint32_t)(leaf_off[l + 1] * m); }
+    PANN_HIP(hipMemcpyAsync(d_seg_b.p, seg_b.data(), nleaves * 4, hipMemcpyHostToDevice, st));
+    PANN_HIP(hipMemcpyAsync(d_seg_e.p, seg_e.data(), nleaves * 4, hipMemcpyHostToDevice, st));
+    size_t tb = sort_tmp;
+    PANN_HIP(rocprim::segmented_radix_sort_keys(b_tmp.p, tb, b_ka.as<uint64_t>(), b_kb.as<uint64_t>(), (unsigned)ne, nleaves,
+                                                (const uint32_t*)d_seg_b.as<uint32_t>(), (const uint32_t*)d_seg_e.as<uint32_t>(), 0, 64, st));
+    MstArgs ma{};
+    ma.keys = b_kb.as<uint64_t>(); ma.leaf_off = d_loff.as<uint64_t>(); ma.nleaves = nleaves; ma.m = m; ma.ids = ids;
+    ma.graph = ix.graph; ma.gstride = ix.gstride; ma.max_deg = ix.max_deg; ma.deg = b_deg.as<uint32_t>(); ma.mst_deg = mst_deg;
+    ma.g_parent = b_par.as<int32_t>(); ma.g_rank = b_rnk.as<uint8_t>(); ma.g_degree = b_dgr.as<uint8_t>();
+    hipLaunchKernelGGL(leaf_mst_kernel, dim3(nleaves), dim3(PANN_WAVE), 4096 * 6, st, ma);
+    PANN_HIP(hipGetLastError());
+    PANN_HIP(hipStreamSynchronize(st));
+    const auto t3 = now();
+    t_tree += secs(t0, t1); t_leaf += secs(t1, t2); t_mst += secs(t2, t3);
+  }
+  if (times3) { times3[0] = t_tree; times3[1] = t_leaf; times3[2] = t_mst; }
+  return PANN_OK;
+}
+
+}  // namespace pann

@@ -85,4 +85,8 @@ int rerank_dev(const DeviceIndex& ix, hipStream_t st, const uint8_t* d_q, uint64
                const uint32_t* d_cand, uint32_t c, const uint32_t* d_cnt, uint32_t k, int resort, uint32_t* d_out_ids,
                float* d_out_dists);
 
+// hcnng_build.hip
+int hcnng_build_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, uint32_t num_clusters, uint32_t cluster_size,
+                    uint32_t mst_deg, uint64_t seed, double* times3);
+
 }  // namespace pann

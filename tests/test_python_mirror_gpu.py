@@ -174,8 +174,10 @@ def test_hcnng_build_identical_to_oracle(oracle, dtype, metric, d):
     same seeding rules, integer-valued data -> the graphs must be identical, slot for slot."""
     X = datasets.sift_like(5000, d, seed=1234, dtype=np.float32)
     X = (X - 128).clip(-127, 127).astype(np.int8) if dtype == np.int8 else X.astype(dtype)
-    G = wrapper.hcnng_build(X, metric, 6, 200, 3, seed=9)
+    G = wrapper.hcnng_build(X, metric, 6, 200, 3, seed=9)                       # all on the device
+    Gh = wrapper.hcnng_build(X, metric, 6, 200, 3, seed=9, host_mirror=True)    # C++ host mirror around the device calls
     Go = oracle.hcnng_build(X, 6, 200, 3, seed=9, metric="l2" if metric == "Euclidian" else "mips")
+    np.testing.assert_array_equal(Gh, Go)
     np.testing.assert_array_equal(G, Go)
 
 
