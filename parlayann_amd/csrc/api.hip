@@ -5,8 +5,6 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
-#include <mutex>
-#include <numeric>
 #include <vector>
 
 #include "pann_internal.h"
@@ -56,7 +54,6 @@ struct pann_index {
   Workspace ws, ws2, ws3;   // kernel scratch (search / prune / re-prune)
   uint32_t vcap = 0;        // visited-list capacity used by the builder (grows on overflow)
   DevBuf stage[12];      // staging for host-pointer calls
-  std::vector<uint32_t> hrow;  // host scratch
 };
 
 namespace {

@@ -415,8 +415,6 @@ static int run_prune(const DeviceIndex& ix, PruneArgs pa, GreedyArgs ga, uint64_
   return PANN_OK;
 }
 
-size_t prune_workspace_bytes(uint64_t m, uint32_t max_cand) { return (size_t)m * max_cand * 16 + (1u << 20); }
-
 // Host-pointer robustPrune batch (the C-ABI entry): stage, run, fetch.
 int robust_prune_batch_host(const DeviceIndex& ix, Workspace& ws, hipStream_t st, const uint32_t* owners,
                             uint64_t m, const uint32_t* cand_ids, const float* cand_dists,

@@ -187,6 +187,15 @@ struct hcnng_index {
     t_mst_s += std::chrono::duration<double>(t2 - t1).count();
   }
 
+  // The same build with the trees and Kruskal on the device as well (one pann_hcnng_build call; identical graph).
+  void build_index_on_device(GraphI& G, PointRange& Points, long cluster_rounds, long cluster_size, long MSTDeg) {
+    DI D(Points, nullptr, G.max_degree(), device);
+    double t3[3] = {0, 0, 0};
+    pann_check(pann_hcnng_build(D.h, (uint32_t)cluster_rounds, (uint32_t)cluster_size, (uint32_t)MSTDeg, seed, t3));
+    t_tree_s += t3[0]; t_leaf_s += t3[1]; t_mst_s += t3[2];
+    D.download_graph(G);
+  }
+
   // build_index(G, Points, cluster_rounds, cluster_size, MSTDeg)   (:273-281)
   void build_index(GraphI& G, PointRange& Points, long cluster_rounds, long cluster_size, long MSTDeg) {
     DI D(Points, nullptr, G.max_degree(), device);

@@ -2,7 +2,7 @@
 // :80-121): builds (Vamana or HCNNG) or loads a graph, runs the fixed-beam query of the `-Q` path
 // (check_nn_recall.h:221-226) and prints recall / QPS.  Flags: -base_path -query_path -gt_path
 // -graph_path -graph_outfile -data_type {uint8,int8,float} -dist_func {Euclidian,mips} -k -Q -R -L
-// -alpha -num_passes -cluster_size -mst_deg -num_clusters -alg {vamana,hcnng} -device -seed
+// -alpha -num_passes -cluster_size -mst_deg -num_clusters -alg {vamana,hcnng} -device -seed -device_build {1,0}
 #include <cstring>
 #include <map>
 #include <string>
@@ -41,7 +41,8 @@ int run(const Args& a) {
     const auto t0 = std::chrono::steady_clock::now();
     if (alg == "hcnng") {
       hcnng_index<Point, PR, indexType> I; I.seed = (uint64_t)a.num("-seed", 1);
-      I.build_index(G, Points, BP.num_clusters, BP.cluster_size, BP.MST_deg);
+      if (a.num("-device_build", 1)) I.build_index_on_device(G, Points, BP.num_clusters, BP.cluster_size, BP.MST_deg);
+      else I.build_index(G, Points, BP.num_clusters, BP.cluster_size, BP.MST_deg);   // host tree + Kruskal around the device calls
       std::cout << "tree time: " << I.t_tree_s << " leaf knn time: " << I.t_leaf_s << " mst time: " << I.t_mst_s << std::endl;
     } else {
       knn_index<PR, indexType> I(BP); I.seed = (uint64_t)a.num("-seed", 1);

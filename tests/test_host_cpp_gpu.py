@@ -76,6 +76,10 @@ def test_hcnng_cli_graph_quality(exe, files):
     _run(exe, "-base_path", d / "base.bin", "-graph_outfile", d / "h2.graph", "-alg", "hcnng", "-data_type", "uint8",
          "-num_clusters", 12, "-cluster_size", 300, "-mst_deg", 3, "-seed", 3)
     np.testing.assert_array_equal(G, io.read_graph(d / "h2.graph"))
+    # the host-mirror path (-device_build 0: host tree + Kruskal around the device calls) gives the same graph
+    _run(exe, "-base_path", d / "base.bin", "-graph_outfile", d / "h3.graph", "-alg", "hcnng", "-data_type", "uint8",
+         "-num_clusters", 12, "-cluster_size", 300, "-mst_deg", 3, "-seed", 3, "-device_build", 0)
+    np.testing.assert_array_equal(G, io.read_graph(d / "h3.graph"))
 
 
 def test_pivot_split_matches_oracle_distances(oracle):
