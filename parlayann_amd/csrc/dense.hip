@@ -3,7 +3,8 @@
 //   hcnng_index::MSTk  HCNNG/hcnng_index.h:145-181  all N*(N-1) leaf distances, 10 smallest per row
 //   compute_groundtruth  data_tools/compute_groundtruth.cpp:22-59  exact kNN of every query
 //
-// Tiling: a 256-thread workgroup owns 64 A-rows (16 per wave) and streams B in tiles of 64 rows;
+// Tiling: a 256-thread workgroup owns 64 A-rows (16 per wave) and streams B in tiles of 128 rows (64 in
+// the MFMA variant);
 // both tiles are staged in LDS in 256-byte dimension segments (B padded by 16 B per row so the
 // lane-per-row ds_read_b128 is conflict free, A read as broadcasts).  Lane l of a wave holds the
 // running distances of B-row l to the wave's 16 A-rows in registers, so a B tile is read from HBM
@@ -20,7 +21,8 @@ namespace pann {
 
 constexpr int DT_A = 64;        // A rows per workgroup
 constexpr int DT_AW = 16;       // A rows per wave
-constexpr int DT_B = 64;        // B rows per tile (one per lane)
+constexpr int DT_B = 64;        // B rows per lane group (one per lane)
+constexpr int DT_RB = 2;        // VALU kernel: B rows per lane (tile = 128 rows); halves the LDS broadcasts per FMA
 constexpr int DT_SEG = 256;     // bytes of the dimension staged per step
 constexpr int DT_BSTRIDE = DT_SEG + 16;
 
@@ -34,7 +36,7 @@ struct DenseArgs {
   const uint64_t* a_off; const uint64_t* b_off;   // device arrays, nseg+1 (null: one segment 0..na / 0..nb)
   uint64_t na, nb;
   uint32_t nsplit;            // B range of a segment is cut into nsplit pieces (grid.y)
-  uint32_t m, mcap;           // top-m; mcap = m rounded up to 64
+  uint32_t m, mcap;           // top-m; mcap = m rounded up to 16
   int exclude_same_id;        // leaf mode: skip j == i (hcnng_index.h:153)
   uint64_t* partial;          // [total A rows][nsplit][m] keys
   const uint32_t* tile_seg;   // [grid.x] segment of each A tile
@@ -72,9 +74,10 @@ template <int DT, int METRIC>
 __global__ void __launch_bounds__(256) dense_topk_kernel(DenseArgs A) {
   extern __shared__ __align__(16) uint8_t smem[];
   uint8_t* At = smem;                                   // [64][DT_SEG]
-  uint8_t* Bt = At + DT_A * DT_SEG;                     // [64][DT_BSTRIDE]
-  uint32_t* Bid = reinterpret_cast<uint32_t*>(Bt + DT_B * DT_BSTRIDE);   // [64] ids of the B tile
-  uint32_t* Aid = Bid + DT_B;                           // [64] ids of the A tile (SENTINEL: none)
+  constexpr int TB = DT_B * DT_RB;                      // B rows per tile: DT_RB per lane
+  uint8_t* Bt = At + DT_A * DT_SEG;                     // [TB][DT_BSTRIDE]
+  uint32_t* Bid = reinterpret_cast<uint32_t*>(Bt + TB * DT_BSTRIDE);     // [TB] ids of the B tile
+  uint32_t* Aid = Bid + TB;                             // [64] ids of the A tile (SENTINEL: none)
   uint64_t* lists = reinterpret_cast<uint64_t*>(Aid + DT_A);            // [64][mcap]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t seg = A.tile_seg ? A.tile_seg[blockIdx.x] : 0u;
@@ -85,7 +88,7 @@ __global__ void __launch_bounds__(256) dense_topk_kernel(DenseArgs A) {
   (void)a_lo;
   // this block's share of the B range
   const uint64_t nb_seg = b_hi - b_lo;
-  const uint64_t per = ((nb_seg + A.nsplit - 1) / A.nsplit + DT_B - 1) / DT_B * DT_B;
+  const uint64_t per = ((nb_seg + A.nsplit - 1) / A.nsplit + TB - 1) / TB * TB;
   const uint64_t bs = b_lo + min(nb_seg, (uint64_t)blockIdx.y * per);
   const uint64_t be = b_lo + min(nb_seg, (uint64_t)(blockIdx.y + 1) * per);
 
@@ -95,9 +98,9 @@ __global__ void __launch_bounds__(256) dense_topk_kernel(DenseArgs A) {
 
   const uint32_t nseg = (A.pstride + DT_SEG - 1) / DT_SEG;
   // stage one 256-byte segment of 64 rows: 16 lanes x 16 B per row, 16 rows per pass of 256 threads
-  auto stage_rows = [&](uint8_t* dst, uint32_t dstride, uint32_t sg, auto rowptr, auto rowvalid, uint32_t nrows) {
+  auto stage_rows = [&](uint8_t* dst, uint32_t dstride, uint32_t sg, auto rowptr, auto rowvalid, uint32_t nrows, int rows_total) {
     const int r0 = tid >> 4, c = tid & 15;
-    for (int r = r0; r < 64; r += 16) {
+    for (int r = r0; r < rows_total; r += 16) {
       uint4 v = make_uint4(0, 0, 0, 0);
       const uint32_t off = sg * DT_SEG + c * 16;
       if (r < (int)nrows) {
@@ -119,58 +122,69 @@ __global__ void __launch_bounds__(256) dense_topk_kernel(DenseArgs A) {
   };
   auto a_valid = [&]() -> uint32_t { return A.a_ids ? A.pstride : A.dbytes; };
 
-  if (nseg == 1) { stage_rows(At, DT_SEG, 0, a_rowptr, a_valid, na_tile); }
+  if (nseg == 1) { stage_rows(At, DT_SEG, 0, a_rowptr, a_valid, na_tile, DT_A); }
 
-  for (uint64_t bt = bs; bt < be; bt += DT_B) {
-    const uint32_t nb_tile = (uint32_t)min((uint64_t)DT_B, be - bt);
+  for (uint64_t bt = bs; bt < be; bt += TB) {
+    const uint32_t nb_tile = (uint32_t)min((uint64_t)TB, be - bt);
     auto b_rowptr = [&](int r) -> const uint8_t* {
       const uint64_t id = A.b_ids ? (uint64_t)A.b_ids[bt + r] : (bt + r);
       return A.points + id * A.pstride;
     };
     auto b_valid = [&]() -> uint32_t { return A.pstride; };
-    Acc<DT> acc[DT_AW];
+    Acc<DT> acc[DT_AW][DT_RB];
 #pragma unroll
-    for (int a = 0; a < DT_AW; a++) acc[a].clear();
+    for (int a = 0; a < DT_AW; a++)
+#pragma unroll
+      for (int rb = 0; rb < DT_RB; rb++) acc[a][rb].clear();
     __syncthreads();          // previous tile's readers are done with Bt / Bid
-    if (tid < DT_B) Bid[tid] = tid < (int)nb_tile ? (A.b_ids ? A.b_ids[bt + tid] : (uint32_t)(bt + tid)) : SENTINEL;
+    if (tid < TB) Bid[tid] = tid < (int)nb_tile ? (A.b_ids ? A.b_ids[bt + tid] : (uint32_t)(bt + tid)) : SENTINEL;
     for (uint32_t sg = 0; sg < nseg; sg++) {
       if (sg > 0) __syncthreads();
-      stage_rows(Bt, DT_BSTRIDE, sg, b_rowptr, b_valid, nb_tile);
-      if (nseg > 1) stage_rows(At, DT_SEG, sg, a_rowptr, a_valid, na_tile);
+      stage_rows(Bt, DT_BSTRIDE, sg, b_rowptr, b_valid, nb_tile, TB);
+      if (nseg > 1) stage_rows(At, DT_SEG, sg, a_rowptr, a_valid, na_tile, DT_A);
       __syncthreads();
       const uint32_t nchunk = min((uint32_t)DT_SEG, A.pstride - sg * DT_SEG) / 16;
       for (uint32_t c = 0; c < nchunk; c++) {
-        // the lane's B chunk is digested once (QReg); the 16 A chunks are LDS broadcasts
-        const QReg<DT> b = make_qreg<DT>(*reinterpret_cast<const uint4*>(Bt + (size_t)lane * DT_BSTRIDE + c * 16));
+        // the lane's DT_RB B chunks are digested once (QReg); each of the 16 A chunks is ONE LDS broadcast
+        // that feeds DT_RB accumulators (the LDS read rate, not the VALU, bounds this loop at DT_RB = 1)
+        QReg<DT> b[DT_RB];
+#pragma unroll
+        for (int rb = 0; rb < DT_RB; rb++)
+          b[rb] = make_qreg<DT>(*reinterpret_cast<const uint4*>(Bt + (size_t)(lane + 64 * rb) * DT_BSTRIDE + c * 16));
 #pragma unroll
         for (int a = 0; a < DT_AW; a++) {
           const uint4 q = *reinterpret_cast<const uint4*>(At + (size_t)(wave * DT_AW + a) * DT_SEG + c * 16);
-          dist_accum<DT, METRIC>(acc[a], q, b);
+#pragma unroll
+          for (int rb = 0; rb < DT_RB; rb++) dist_accum<DT, METRIC>(acc[a][rb], q, b[rb]);
         }
       }
     }
     // ---- top-m update: wave-private lists of its 16 A rows ----
-    const uint32_t bid = Bid[lane];
 #pragma unroll
-    for (int a = 0; a < DT_AW; a++) {
-      const uint32_t ar = wave * DT_AW + a;
-      if (ar >= na_tile) break;               // uniform per wave
-      uint64_t* list = lists + (size_t)ar * A.mcap;
-      const float dist = dist_finish<DT, METRIC>(acc_lane_value<DT, METRIC>(acc[a]));
-      const uint64_t key = make_key(dist, bid);
-      bool ok = (lane < (int)nb_tile);
-      if (A.exclude_same_id) ok = ok && (bid != Aid[ar]);
-      uint64_t tau = list[A.m - 1];
-      uint64_t mask = __ballot(ok && key < tau);
-      while (mask) {
-        const int L = __ffsll((unsigned long long)mask) - 1;
-        const uint32_t klo = __builtin_amdgcn_readlane((uint32_t)key, L);
-        const uint32_t khi = __builtin_amdgcn_readlane((uint32_t)(key >> 32), L);
-        const uint64_t x = ((uint64_t)khi << 32) | klo;
-        mask &= mask - 1;
-        if (x < tau) {
-          list_insert(list, A.mcap, x, lane);
-          tau = list[A.m - 1];
+    for (int rb = 0; rb < DT_RB; rb++) {
+      const uint32_t brow = lane + 64 * rb;
+      const uint32_t bid = Bid[brow];
+#pragma unroll
+      for (int a = 0; a < DT_AW; a++) {
+        const uint32_t ar = wave * DT_AW + a;
+        if (ar >= na_tile) break;               // uniform per wave
+        uint64_t* list = lists + (size_t)ar * A.mcap;
+        const float dist = dist_finish<DT, METRIC>(acc_lane_value<DT, METRIC>(acc[a][rb]));
+        const uint64_t key = make_key(dist, bid);
+        bool ok = (brow < nb_tile);
+        if (A.exclude_same_id) ok = ok && (bid != Aid[ar]);
+        uint64_t tau = list[A.m - 1];
+        uint64_t mask = __ballot(ok && key < tau);
+        while (mask) {
+          const int L = __ffsll((unsigned long long)mask) - 1;
+          const uint32_t klo = __builtin_amdgcn_readlane((uint32_t)key, L);
+          const uint32_t khi = __builtin_amdgcn_readlane((uint32_t)(key >> 32), L);
+          const uint64_t x = ((uint64_t)khi << 32) | klo;
+          mask &= mask - 1;
+          if (x < tau) {
+            list_insert(list, A.mcap, x, lane);
+            tau = list[A.m - 1];
+          }
         }
       }
     }
@@ -353,7 +367,7 @@ __global__ void __launch_bounds__(64) dense_merge_kernel(const uint64_t* partial
 // ---------------------------------------------------------------------------------------------
 
 static size_t dense_lds_bytes(uint32_t mcap) {
-  return (size_t)DT_A * DT_SEG + (size_t)DT_B * DT_BSTRIDE + (DT_A + DT_B) * 4 + (size_t)DT_A * mcap * 8;
+  return (size_t)DT_A * DT_SEG + (size_t)DT_B * DT_RB * DT_BSTRIDE + (DT_A + DT_B * DT_RB) * 4 + (size_t)DT_A * mcap * 8;
 }
 
 // Runs the dense top-m.  All pointers device.  tile arrays may be null for a single segment.
@@ -363,7 +377,7 @@ int dense_topk_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, const u
                    uint32_t nsplit, uint32_t m, int exclude_same, uint32_t* d_out_ids, float* d_out_dists) {
   if (m == 0 || m > 128) { set_error("dense top-m: m must be in [1,128]"); return PANN_ERR_BAD_ARG; }
   if (na == 0) return PANN_OK;
-  const uint32_t mcap = (m + 63) / 64 * 64;
+  const uint32_t mcap = (m + 15) / 16 * 16;
   const size_t pbytes = (size_t)na * nsplit * m * 8;
   if (int rc = ws.ensure(pbytes + 256)) return rc;
   DenseArgs A{};
