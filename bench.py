@@ -55,11 +55,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible and there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU.  (Rehearsals of N ranks on a box with fewer GPUs: ranks wrap around the visible
+    # devices and PANN_BENCH_BACKEND=gloo replaces RCCL, which cannot put two ranks on one device.)
+    dev_ord = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_ord)
+    dev = torch.device("cuda", dev_ord)
+    backend = os.environ.get("PANN_BENCH_BACKEND", "nccl")
     if "RANK" in os.environ:   # launched by torch.distributed.run (also with one rank: same code path)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)   # RCCL; used only for barriers + max-over-ranks
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL; used only for barriers + max-over-ranks
+        else:
+            dist.init_process_group(backend)
 
     # ---- synthetic SIFT-1M-shaped data: integer-valued in [0,255] (see datasets.sift1m_like: difficulty calibrated at n = 1M) ----
     t0 = time.time()
@@ -70,7 +77,7 @@ def main():
     log(f"[rank {rank}] data generated in {time.time() - t0:.1f}s")
 
     # ---- index: replicated on every GPU, built on the device by the product's own builder ----
-    ix = DeviceIndex(X, max_degree=args.R, device=local_rank)
+    ix = DeviceIndex(X, max_degree=args.R, device=dev_ord)
     t0 = time.time()
     bst = ix.vamana_build(args.R, args.L, args.alpha, num_passes=args.passes, seed=1, sort_neighbors=True)
     build_s = time.time() - t0
@@ -112,7 +119,8 @@ def main():
         a, b = next(it)
         a.record(stream); step(); b.record(stream)
 
-    elapsed = D.timed_steps(timed_step, args.steps, args.warmup, sync=lambda: torch.cuda.synchronize(dev), device=dev)
+    elapsed = D.timed_steps(timed_step, args.steps, args.warmup, sync=lambda: torch.cuda.synchronize(dev),
+                            device=dev if backend == "nccl" else None)
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     ms_per_step = elapsed * 1e3 / args.steps
     qps = args.nq * world / (ms_per_step / 1e3)
