@@ -610,6 +610,207 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES_B64) beam_search_b64_
   }
 }
 
+// =============================================================================================
+// 64 < beam <= 128 (the builder's L = 128): the same register-resident frontier with TWO entries
+// per lane (entry e lives in lane e % 64, slot e / 64).  LDS per query: the 16 KB filter + a 128-entry
+// scatter scratch + candidates = 18.2 KB -> 9 queries per CU (the LDS-frontier kernel needs 19.9 KB).
+// =============================================================================================
+template <int DT, int METRIC, int LPC, bool NCH1>
+__global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P) {
+  constexpr int RB = 2;
+  const int lane = threadIdx.x;
+  extern __shared__ __align__(16) uint8_t smem[];
+  uint64_t* S = reinterpret_cast<uint64_t*>(smem);          // [128] merge scatter scratch; first 256 B double as Pl
+  uint64_t* C = S + 64 * RB;                                // [ccap] candidates (unsorted)
+  uint8_t* Sv = reinterpret_cast<uint8_t*>(C + P.ccap);     // [128] flags of the scatter scratch
+  uint4* qlds = reinterpret_cast<uint4*>(Sv + 64 * RB);     // [nch*LPC] query (generic variant)
+  uint32_t* H = reinterpret_cast<uint32_t*>(qlds + (NCH1 ? 0 : P.nch * LPC));  // [1<<bits]
+  uint32_t* Pl = reinterpret_cast<uint32_t*>(S);
+
+  const uint32_t hsize = 1u << P.bits, hmask = hsize - 1u;
+  const uint32_t beam = P.beam;
+  const uint32_t BIG_ORD = f2ord(2147483648.0f);
+  const uint32_t qi = blockIdx.x;
+
+  for (uint32_t i = lane; i < hsize; i += PANN_WAVE) H[i] = SENTINEL;
+  const int64_t self = P.query_ids ? (int64_t)P.query_ids[qi] : -1;
+  const uint8_t* qrow = P.query_ids ? P.points + (uint64_t)self * P.pstride : P.queries + (uint64_t)qi * P.qstride;
+  QReg<DT> qreg{};
+  load_query<DT, LPC, NCH1>(qrow, P.dbytes, P.nch, qreg, qlds, lane);
+  __syncthreads();
+
+  uint32_t f = 0, c = 0, nvis = 0, dcmps = P.nstarts, degsum = 0, ndrop = 0;
+  uint64_t fkey[RB] = {KEY_INF, KEY_INF};
+  uint32_t fflag[RB] = {0, 0};
+  uint64_t* DL = P.dropped + (size_t)qi * P.dcap;
+  auto entry_key = [&](uint32_t e) -> uint64_t {            // uniform e
+    return (e < 64) ? readlane64(fkey[0], (int)e) : readlane64(fkey[1], (int)e - 64);
+  };
+
+  {   // start points (:66-70); nstarts <= 64 in this kernel
+    const bool act = lane < (int)P.nstarts;
+    const uint32_t a = act ? P.starts[(size_t)qi * P.starts_stride + lane] : 0u;
+    (void)filter_update<true>(H, hmask, act, a, lane);
+    if (act) Pl[lane] = a;
+    __syncthreads();
+    c = gather_distances<DT, METRIC, LPC, NCH1, 4>(P, qreg, qlds, Pl, P.nstarts, 0xFFFFFFFFu, C, c, lane);
+    __syncthreads();
+  }
+
+  bool first = true;
+  for (;;) {
+    bool do_merge = first;
+    if (!first) {
+      const uint64_t um0 = __ballot(lane < (int)f && fflag[0] == 0);
+      const uint64_t um1 = __ballot(lane + 64 < (int)f && fflag[1] == 0);
+      if ((um0 | um1) == 0ull || nvis >= P.limit) break;
+      const int cur_idx = um0 ? __ffsll((unsigned long long)um0) - 1 : 64 + __ffsll((unsigned long long)um1) - 1;
+      const bool more_unvisited = (__popcll(um0) + __popcll(um1)) > 1;          // offset + 1 < remain (:165)
+      const uint64_t cur_key = entry_key((uint32_t)cur_idx);
+      const uint32_t cur = key_id(cur_key);
+      if (cur_idx < 64) { if (lane == cur_idx) fflag[0] = 1; } else { if (lane == cur_idx - 64) fflag[1] = 1; }
+      if (lane == 0 && P.out.visited_cap) {
+        if (nvis < P.out.visited_cap) {
+          if (P.out.visited_ids) P.out.visited_ids[(size_t)qi * P.out.visited_cap + nvis] = cur;
+          if (P.out.visited_dists) P.out.visited_dists[(size_t)qi * P.out.visited_cap + nvis] = key_dist(cur_key);
+        } else {
+          atomicOr(P.status, 1u);
+        }
+      }
+      nvis++;
+      uint32_t cutoff_ord = BIG_ORD;
+      if (f == beam) cutoff_ord = (uint32_t)(entry_key(f - 1) >> 32);
+
+      const uint32_t* row = P.graph + (size_t)cur * P.gstride;
+      for (uint32_t i0 = 0; i0 < P.gstride; i0 += PANN_WAVE) {
+        const uint32_t i = i0 + lane;
+        uint32_t a = SENTINEL;
+        if (i < P.gstride) a = row[i];
+        const bool act = (a != SENTINEL) && (i < P.degree_limit);
+        const uint64_t am = __ballot(act);
+        if (am == 0ull) break;
+        degsum += __popcll(am);
+        const bool seen = filter_update<true>(H, hmask, act, a, lane);
+        const bool keep = act && !seen && ((int64_t)a != self);
+        const uint64_t km = __ballot(keep);
+        const uint32_t m = __popcll(km);
+        if (keep) Pl[lanes_below(km, lane)] = a;
+        dcmps += m;
+        __syncthreads();
+        if (m) c = gather_distances<DT, METRIC, LPC, NCH1, PANN_GU>(P, qreg, qlds, Pl, m, cutoff_ord, C, c, lane);
+        __syncthreads();
+      }
+      const bool skip = (c == 0) || (P.skip_enabled && c < beam / 8 && more_unvisited);
+      do_merge = !skip;
+    }
+    if (do_merge) {
+      const uint32_t f_old = f;
+      const bool track = P.cut_enabled && !first;
+      uint32_t lt = 0;
+      for (uint32_t c0 = 0; c0 < c; c0 += PANN_WAVE) {
+        const uint32_t cc = min(c - c0, (uint32_t)PANN_WAVE);
+        const uint64_t ckey = (lane < (int)cc) ? C[c0 + lane] : KEY_INF;
+        const bool fl[RB] = {lane < (int)f, lane + 64 < (int)f};
+        uint32_t myp = 0, rank_c = 0, below_f[RB] = {0, 0};
+        uint64_t live_mask = 0;
+        for (uint32_t i = 0; i < cc; i++) {
+          const uint64_t kk = readlane64(ckey, (int)i);
+          const uint64_t lt0 = __ballot(fl[0] && fkey[0] < kk), lt1 = __ballot(fl[1] && fkey[1] < kk);
+          const uint64_t eq0 = __ballot(fl[0] && fkey[0] == kk), eq1 = __ballot(fl[1] && fkey[1] == kk);
+          const uint64_t dupm = __ballot(lane < (int)i && ckey == kk);
+          if ((eq0 | eq1) == 0ull && dupm == 0ull) {
+            live_mask |= 1ull << i;
+            if (lane == (int)i) myp = __popcll(lt0) + __popcll(lt1);
+            rank_c += (kk < ckey) ? 1u : 0u;
+            below_f[0] += (kk < fkey[0]) ? 1u : 0u;
+            below_f[1] += (kk < fkey[1]) ? 1u : 0u;
+          }
+        }
+        const uint32_t nvalid = __popcll(live_mask);
+        const bool clive = (lane < (int)cc) && ((live_mask >> lane) & 1ull);
+        const uint32_t cpos = rank_c + myp;
+        if (clive && cpos < beam) {
+          uint32_t flag = 0u;
+          for (uint32_t t = 0; t < ndrop; t++)
+            flag |= (__hip_atomic_load(DL + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ckey) ? 2u : 0u;
+          S[cpos] = ckey; Sv[cpos] = (uint8_t)flag;
+        }
+#pragma unroll
+        for (int r = 0; r < RB; r++) {
+          const uint32_t fpos = (uint32_t)lane + 64 * r + below_f[r];
+          if (fl[r] && fpos < beam) { S[fpos] = fkey[r]; Sv[fpos] = (uint8_t)fflag[r]; }
+          if (track) {
+            const bool lost = fl[r] && fflag[r] == 1u && fpos >= beam;
+            const uint64_t lm = __ballot(lost);
+            if (lost) {
+              const uint32_t at = ndrop + lt + lanes_below(lm, lane);
+              if (at < P.dcap) DL[at] = fkey[r]; else atomicOr(P.status, 2u);
+            }
+            lt += __popcll(lm);
+          }
+        }
+        __syncthreads();
+        f = min(f + nvalid, beam);
+#pragma unroll
+        for (int r = 0; r < RB; r++) {
+          const bool in = lane + 64 * r < (int)f;
+          fkey[r] = in ? S[lane + 64 * r] : KEY_INF;
+          fflag[r] = in ? (uint32_t)Sv[lane + 64 * r] : 0u;
+        }
+        __syncthreads();
+      }
+      uint32_t f_new = f;
+      if (!first && P.cut_enabled && f_new > P.k) {
+        const float dk = key_dist(entry_key(P.k));
+        const float thr = (float)(P.cut * (double)dk);
+        const uint64_t thr_key = (uint64_t)f2ord(thr) << 32;
+        const uint32_t ub = __popcll(__ballot(lane < (int)f_new && fkey[0] <= thr_key)) +
+                            __popcll(__ballot(lane + 64 < (int)f_new && fkey[1] <= thr_key));
+        f_new = max(ub, f_old);
+      }
+      if (f_new == beam) {
+        ndrop = 0;
+      } else if (track) {
+#pragma unroll
+        for (int r = 0; r < RB; r++) {
+          const int e = lane + 64 * r;
+          const bool lost = e >= (int)f_new && e < (int)f && fflag[r] == 1u;
+          const uint64_t lm = __ballot(lost);
+          if (lost) {
+            const uint32_t at = ndrop + lt + lanes_below(lm, lane);
+            if (at < P.dcap) DL[at] = fkey[r]; else atomicOr(P.status, 2u);
+          }
+          lt += __popcll(lm);
+        }
+        ndrop = min(ndrop + lt, P.dcap);
+        if (lt) __builtin_amdgcn_s_waitcnt(0);
+      }
+      f = f_new;
+#pragma unroll
+      for (int r = 0; r < RB; r++) if (lane + 64 * r >= (int)f) { fkey[r] = KEY_INF; fflag[r] = 0u; }
+      c = 0;
+    }
+    first = false;
+  }
+
+  const size_t qo = (size_t)qi * P.out.out_k;
+#pragma unroll
+  for (int r = 0; r < RB; r++) {
+    const uint32_t j = lane + 64 * r;
+    if (j < P.out.out_k) {
+      const bool ok = j < f;
+      if (P.out.ids) P.out.ids[qo + j] = ok ? key_id(fkey[r]) : SENTINEL;
+      if (P.out.dists) P.out.dists[qo + j] = ok ? key_dist(fkey[r]) : __builtin_inff();
+    }
+  }
+  if (lane == 0) {
+    if (P.out.frontier_size) P.out.frontier_size[qi] = f;
+    if (P.out.visited_count) P.out.visited_count[qi] = nvis;
+    if (P.out.dist_cmps) P.out.dist_cmps[qi] = dcmps;
+    if (P.out.degree_sum) P.out.degree_sum[qi] = degsum;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side: layout choice, LDS budget, dispatch
 // ---------------------------------------------------------------------------------------------
@@ -633,7 +834,7 @@ static uint32_t filter_bits(int64_t beam) {  // :52
 }
 
 struct Plan {
-  uint32_t bits, bcap, ccap, deg_eff, dcap, lds_bytes; bool hash_lds; uint32_t slots; bool b64;
+  uint32_t bits, bcap, ccap, deg_eff, dcap, lds_bytes; bool hash_lds; uint32_t slots; bool b64; bool b128;
 };
 
 static Plan make_plan(const DeviceIndex& ix, const SearchArgs& a) {
@@ -658,6 +859,11 @@ static Plan make_plan(const DeviceIndex& ix, const SearchArgs& a) {
     p.ccap = (std::max<uint32_t>(beam / 8 + p.deg_eff, a.nstarts) + 7) / 8 * 8;
     p.lds_bytes = (uint32_t)(64 * 8 + (size_t)p.ccap * 8 + 64 + (nch1 ? 0 : (size_t)ix.nch * ix.lpc * 16) + hbytes);
   }
+  p.b128 = p.hash_lds && p.bcap == 128 && a.nstarts <= 64;
+  if (p.b128) {
+    p.ccap = (std::max<uint32_t>(beam / 8 + p.deg_eff, a.nstarts) + 7) / 8 * 8;
+    p.lds_bytes = (uint32_t)(128 * 8 + (size_t)p.ccap * 8 + 128 + (nch1 ? 0 : (size_t)ix.nch * ix.lpc * 16) + hbytes);
+  }
   return p;
 }
 
@@ -673,6 +879,9 @@ template <int DT, int METRIC, int LPC, bool NCH1>
 static hipError_t launch_variant(const BSParams& P, const Plan& p, hipStream_t stream) {
   if (p.b64) {   // frontier in registers
     auto kern = beam_search_b64_kernel<DT, METRIC, LPC, NCH1>;
+    hipLaunchKernelGGL(kern, dim3(P.nq), dim3(PANN_WAVE), p.lds_bytes, stream, P);
+  } else if (p.b128) {   // two frontier entries per lane
+    auto kern = beam_search_b128_kernel<DT, METRIC, LPC, NCH1>;
     hipLaunchKernelGGL(kern, dim3(P.nq), dim3(PANN_WAVE), p.lds_bytes, stream, P);
   } else if (p.hash_lds) {
     auto kern = beam_search_kernel<DT, METRIC, LPC, NCH1, true>;
