@@ -1,119 +1,147 @@
-// graph.h -- host mirror of algorithms/utils/graph.h: Graph<indexType> (:125-250) and edgeRange
-// (:41-123).  Flat n x (maxDeg+1) slab, slot 0 = degree; same file format (:155-160,:210-231).
+// graph.h -- host mirror of the Graph / edgeRange SURFACE of algorithms/utils/graph.h (edgeRange :41-123,
+// Graph :125-250): same type names, methods, in-memory row layout (n rows of maxDeg+1 ids, slot 0 = degree)
+// and file format ([n][maxDeg][degree of every vertex][all edges], :155-160,:210-231), written for this
+// repo: one zero-initialised slab, C stdio for the files, a single bounds/abort helper.
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <fstream>
 #include <iostream>
 #include <memory>
 #include <vector>
 
 namespace parlayANN {
 
+namespace graph_detail {
+[[noreturn]] inline void die(const char* what, long value) {
+  // the reference reports on stdout and aborts (graph.h:56-58,63-66,235-238)
+  std::cout << what << value << std::endl;
+  std::abort();
+}
+inline size_t round_up_2mb(size_t bytes) {
+  const size_t two_mb = size_t(1) << 21;
+  return std::max(two_mb, (bytes + two_mb - 1) / two_mb * two_mb);
+}
+}  // namespace graph_detail
+
+// view of one adjacency row: row[0] = degree, row[1 .. degree] = neighbours
 template <typename indexType>
 struct edgeRange {
-  size_t size() const { return edges[0]; }
-  indexType id() const { return id_; }
-  edgeRange() : edges(nullptr), maxDeg(0) {}
-  edgeRange(indexType* start, indexType* end, indexType id) : edges(start), maxDeg((long)(end - start - 1)), id_(id) {}
+  edgeRange() = default;
+  edgeRange(indexType* first, indexType* last, indexType owner) : row_(first), cap_(last - first - 1), owner_(owner) {}
+
+  size_t size() const { return row_[0]; }
+  indexType id() const { return owner_; }
 
   indexType operator[](indexType j) const {
-    if (j > edges[0]) { std::cout << "ERROR: index exceeds degree while accessing neighbors" << std::endl; abort(); }
-    return edges[j + 1];
+    if (j > row_[0]) graph_detail::die("ERROR: index exceeds degree while accessing neighbors: ", (long)j);
+    return row_[1 + j];
   }
+
   void append_neighbor(indexType nbh) {
-    if (edges[0] == (indexType)maxDeg) { std::cout << "ERROR in append_neighbor: cannot exceed max degree " << maxDeg << std::endl; abort(); }
-    edges[edges[0] + 1] = nbh;
-    edges[0] += 1;
+    if ((long)row_[0] == cap_) graph_detail::die("ERROR in append_neighbor: cannot exceed max degree ", cap_);
+    row_[++row_[0]] = nbh;
   }
-  template <typename rangeType>
-  void update_neighbors(const rangeType& r) {
-    if ((long)r.size() > maxDeg) { std::cout << "ERROR in update_neighbors: cannot exceed max degree " << maxDeg << std::endl; abort(); }
-    edges[0] = (indexType)r.size();
-    for (size_t i = 0; i < r.size(); i++) edges[i + 1] = r[i];
-  }
+
   template <typename rangeType>
   void append_neighbors(const rangeType& r) {
-    if ((long)(r.size() + edges[0]) > maxDeg) { std::cout << "ERROR in append_neighbors for point " << id_ << ": cannot exceed max degree " << maxDeg << std::endl; abort(); }
-    for (size_t i = 0; i < r.size(); i++) edges[edges[0] + i + 1] = r[i];
-    edges[0] += (indexType)r.size();
+    if ((long)(row_[0] + r.size()) > cap_)
+      graph_detail::die("ERROR in append_neighbors: cannot exceed max degree ", cap_);
+    indexType* out = row_ + 1 + row_[0];
+    for (size_t i = 0; i < r.size(); i++) out[i] = r[i];
+    row_[0] += (indexType)r.size();
   }
-  void clear_neighbors() { edges[0] = 0; }
+
+  template <typename rangeType>
+  void update_neighbors(const rangeType& r) {
+    if ((long)r.size() > cap_) graph_detail::die("ERROR in update_neighbors: cannot exceed max degree ", cap_);
+    for (size_t i = 0; i < r.size(); i++) row_[1 + i] = r[i];
+    row_[0] = (indexType)r.size();
+  }
+
+  void clear_neighbors() { row_[0] = 0; }
+
   template <typename F>
-  void sort(F&& less) { std::sort(edges + 1, edges + 1 + edges[0], less); }
-  indexType* begin() { return edges + 1; }
-  indexType* end() { return edges + 1 + edges[0]; }
+  void sort(F&& less) { std::sort(begin(), end(), less); }
+
+  indexType* begin() { return row_ + 1; }
+  indexType* end() { return row_ + 1 + row_[0]; }
 
  private:
-  indexType* edges;
-  long maxDeg;
-  indexType id_;
+  indexType* row_ = nullptr;
+  long cap_ = 0;
+  indexType owner_ = 0;
 };
 
 template <typename indexType_>
 struct Graph {
   using indexType = indexType_;
-  long max_degree() const { return maxDeg; }
-  size_t size() const { return n; }
-  indexType* data() { return graph.get(); }
-  const indexType* data() const { return graph.get(); }
 
-  Graph() {}
-  Graph(long maxDeg, size_t n) : n(n), maxDeg(maxDeg) { allocate_graph(maxDeg, n); }
+  Graph() = default;
+  Graph(long maxDeg, size_t n) : n_(n), max_deg_(maxDeg) { allocate(); }
 
-  explicit Graph(const char* gFile) {     // :147-204
-    std::ifstream reader(gFile, std::ios::binary);
-    if (!reader.is_open()) { std::cout << "graph file " << gFile << " not found" << std::endl; abort(); }
-    indexType num_points, max_deg;
-    reader.read((char*)&num_points, sizeof(indexType));
-    reader.read((char*)&max_deg, sizeof(indexType));
-    n = num_points; maxDeg = max_deg;
-    std::cout << "Graph: detected " << num_points << " points with max degree " << max_deg << std::endl;
-    std::vector<indexType> degrees(n);
-    reader.read((char*)degrees.data(), (std::streamsize)(sizeof(indexType) * n));
-    allocate_graph(maxDeg, n);
+  // [n][maxDeg][deg_0 .. deg_{n-1}][edges of vertex 0][edges of vertex 1]...
+  explicit Graph(const char* gFile) {
+    FILE* f = std::fopen(gFile, "rb");
+    if (!f) { std::cout << "graph file " << gFile << " not found" << std::endl; std::abort(); }
+    indexType header[2];
+    if (std::fread(header, sizeof(indexType), 2, f) != 2) graph_detail::die("graph file too short: ", 0);
+    n_ = header[0];
+    max_deg_ = header[1];
+    std::cout << "Graph: detected " << n_ << " points with max degree " << max_deg_ << std::endl;
+    allocate();
+    std::vector<indexType> degrees(n_);
+    if (n_ && std::fread(degrees.data(), sizeof(indexType), n_, f) != n_) graph_detail::die("graph file too short: ", 1);
     size_t total = 0;
-    std::vector<indexType> buf;
-    for (size_t i = 0; i < n; i++) {
-      indexType* row = graph.get() + i * (maxDeg + 1);
-      row[0] = degrees[i];
-      reader.read((char*)(row + 1), (std::streamsize)(sizeof(indexType) * degrees[i]));
-      total += degrees[i];
+    for (size_t v = 0; v < n_; v++) {
+      indexType* row = row_ptr(v);
+      const size_t d = std::min<size_t>(degrees[v], (size_t)max_deg_);
+      if (d && std::fread(row + 1, sizeof(indexType), d, f) != d) graph_detail::die("graph file too short: ", 2);
+      if (degrees[v] > d) std::fseek(f, (long)((degrees[v] - d) * sizeof(indexType)), SEEK_CUR);
+      row[0] = (indexType)d;
+      total += d;
     }
+    std::fclose(f);
     std::cout << "Total edges read from file: " << total << std::endl;
   }
 
-  void save(const char* oFile) {         // :206-232
-    std::cout << "Writing graph with " << n << " points and max degree " << maxDeg << std::endl;
-    std::ofstream writer(oFile, std::ios::binary | std::ios::out);
-    indexType pre[2] = {(indexType)n, (indexType)maxDeg};
-    writer.write((char*)pre, 2 * sizeof(indexType));
-    std::vector<indexType> sizes(n);
-    for (size_t i = 0; i < n; i++) sizes[i] = graph.get()[i * (maxDeg + 1)];
-    writer.write((char*)sizes.data(), (std::streamsize)(n * sizeof(indexType)));
-    for (size_t i = 0; i < n; i++)
-      writer.write((char*)(graph.get() + i * (maxDeg + 1) + 1), (std::streamsize)(sizes[i] * sizeof(indexType)));
-    writer.close();
+  void save(const char* oFile) const {
+    std::cout << "Writing graph with " << n_ << " points and max degree " << max_deg_ << std::endl;
+    FILE* f = std::fopen(oFile, "wb");
+    if (!f) graph_detail::die("cannot open graph output file: ", 0);
+    const indexType header[2] = {(indexType)n_, (indexType)max_deg_};
+    std::fwrite(header, sizeof(indexType), 2, f);
+    std::vector<indexType> degrees(n_);
+    for (size_t v = 0; v < n_; v++) degrees[v] = row_ptr(v)[0];
+    std::fwrite(degrees.data(), sizeof(indexType), n_, f);
+    for (size_t v = 0; v < n_; v++) std::fwrite(row_ptr(v) + 1, sizeof(indexType), degrees[v], f);
+    std::fclose(f);
   }
 
-  edgeRange<indexType> operator[](indexType i) const {
-    if (i > n) { std::cout << "ERROR: graph index out of range: " << i << std::endl; abort(); }
-    return edgeRange<indexType>(graph.get() + (size_t)i * (maxDeg + 1), graph.get() + ((size_t)i + 1) * (maxDeg + 1), i);
+  long max_degree() const { return max_deg_; }
+  size_t size() const { return n_; }
+  indexType* data() { return slab_.get(); }
+  const indexType* data() const { return slab_.get(); }
+
+  edgeRange<indexType> operator[](indexType v) const {
+    if (v > n_) graph_detail::die("ERROR: graph index out of range: ", (long)v);
+    indexType* row = row_ptr(v);
+    return edgeRange<indexType>(row, row + max_deg_ + 1, v);
   }
 
  private:
-  void allocate_graph(long maxDeg_, size_t n_) {
-    const size_t cnt = n_ * (size_t)(maxDeg_ + 1);
-    const size_t bytes = std::max<size_t>((cnt * sizeof(indexType) + ((1ul << 21) - 1)) & ~((1ul << 21) - 1), 1ul << 21);
-    indexType* ptr = (indexType*)aligned_alloc(1l << 21, bytes);
-    std::memset(ptr, 0, bytes);
-    graph = std::shared_ptr<indexType[]>(ptr, std::free);
+  indexType* row_ptr(size_t v) const { return slab_.get() + v * (size_t)(max_deg_ + 1); }
+  void allocate() {
+    const size_t bytes = graph_detail::round_up_2mb(n_ * (size_t)(max_deg_ + 1) * sizeof(indexType));
+    void* p = aligned_alloc(size_t(1) << 21, bytes);       // 2 MiB aligned like the reference slab (graph.h:136)
+    std::memset(p, 0, bytes);
+    slab_ = std::shared_ptr<indexType[]>(static_cast<indexType*>(p), std::free);
   }
-  size_t n = 0;
-  long maxDeg = 0;
-  std::shared_ptr<indexType[]> graph;
+  size_t n_ = 0;
+  long max_deg_ = 0;
+  std::shared_ptr<indexType[]> slab_;
 };
 
 }  // namespace parlayANN
