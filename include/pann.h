@@ -108,6 +108,12 @@ uint32_t pann_index_dims(const pann_index* idx);
 uint32_t pann_index_max_degree(const pann_index* idx);
 int pann_index_device(const pann_index* idx);
 
+/* Validation mode for float element types (f32, f16): every distance is summed strictly left to right
+ * with one rounding per subtract / multiply / add, as the reference's scalar loops do
+ * (euclidian_point.h:83-90, mips_point.h:59-65), so results on REAL-valued data are bit-identical to
+ * the CPU path (one lane per candidate: several times slower).  No effect on integer types. */
+int pann_index_set_exact_float_order(pann_index* idx, int on);
+
 /* Replace the whole graph from a host n x (max_deg+1) slab. */
 int pann_index_set_graph(pann_index* idx, const uint32_t* graph);
 /* Replace m rows: rows is m x (max_deg+1) in the reference layout (edgeRange::update_neighbors,

@@ -59,6 +59,7 @@ SIGNATURES = {
     "pann_index_dims": (C.c_uint32, [C.c_void_p]),
     "pann_index_max_degree": (C.c_uint32, [C.c_void_p]),
     "pann_index_device": (C.c_int, [C.c_void_p]),
+    "pann_index_set_exact_float_order": (C.c_int, [C.c_void_p, C.c_int]),
     "pann_index_set_graph": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pann_index_update_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "pann_index_get_graph": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -219,6 +219,15 @@ uint32_t pann_index_dims(const pann_index* idx) { return idx ? idx->ix.d : 0; }
 uint32_t pann_index_max_degree(const pann_index* idx) { return idx ? idx->ix.max_deg : 0; }
 int pann_index_device(const pann_index* idx) { return idx ? idx->device : -1; }
 
+int pann_index_set_exact_float_order(pann_index* idx, int on) {
+  if (int rc = check_idx(idx, "pann_index_set_exact_float_order")) return rc;
+  DeviceIndex& ix = idx->ix;
+  const bool is_float = ix.dtype == PANN_F32 || ix.dtype == PANN_F16;
+  if (on && is_float) { ix.exact = 1; ix.lpc = 4; ix.nch = ix.pstride / 64; }   // whole query in LDS, lane-per-candidate sums
+  else { ix.exact = 0; choose_point_layout(ix.dbytes, &ix.lpc, &ix.nch); }
+  return PANN_OK;
+}
+
 int pann_index_set_graph(pann_index* idx, const uint32_t* graph) {
   if (int rc = check_idx(idx, "pann_index_set_graph")) return rc;
   if (!graph) { set_error("pann_index_set_graph: null graph"); return PANN_ERR_BAD_ARG; }

@@ -55,7 +55,7 @@ namespace pann {
 #endif
 
 struct BSParams {
-  const uint8_t* points; uint32_t pstride; uint32_t dbytes; uint32_t nch;
+  const uint8_t* points; uint32_t pstride; uint32_t dbytes; uint32_t nch; uint32_t exact;
   const uint32_t* graph; uint32_t gstride; uint32_t max_deg;
   const uint8_t* queries; uint64_t qstride; const uint32_t* query_ids;
   const uint32_t* starts; uint32_t nstarts; uint32_t starts_stride;   // starts_stride: 0 shared, nstarts per query
@@ -140,7 +140,7 @@ template <int DT, int METRIC, int LPC, bool NCH1, int U>
 __device__ __forceinline__ uint32_t gather_distances(const BSParams& P, const QReg<DT>& qreg,
                                                      const uint4* qlds, const uint32_t* Pl, uint32_t m,
                                                      uint32_t cutoff_ord, uint64_t* C, uint32_t c, int lane) {
-  const PointsView PV{P.points, P.pstride, P.nch};
+  const PointsView PV{P.points, P.pstride, P.nch, P.exact};
   gather_tile<DT, METRIC, LPC, NCH1, U>(PV, qreg, qlds, Pl, m, lane,
     [&](bool has, uint32_t, uint32_t id, float dist) {
       const uint32_t ord = f2ord(dist);
@@ -930,7 +930,7 @@ int launch_beam_search(const DeviceIndex& ix, const SearchArgs& a, void* ws, siz
   if (search_workspace_bytes(ix, a) > ws_bytes) { set_error("pann_batch_search: workspace too small"); return PANN_ERR_BAD_ARG; }
 
   BSParams P;
-  P.points = ix.points; P.pstride = ix.pstride; P.dbytes = ix.dbytes; P.nch = ix.nch;
+  P.points = ix.points; P.pstride = ix.pstride; P.dbytes = ix.dbytes; P.nch = ix.nch; P.exact = ix.exact;
   P.graph = ix.graph; P.gstride = ix.gstride; P.max_deg = ix.max_deg;
   P.queries = a.queries; P.qstride = a.qstride; P.query_ids = a.query_ids;
   P.starts = a.starts; P.nstarts = a.nstarts; P.starts_stride = a.starts_per_query ? a.nstarts : 0u; P.nq = (uint32_t)a.nq;

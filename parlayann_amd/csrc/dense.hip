@@ -38,6 +38,7 @@ struct DenseArgs {
   uint32_t nsplit;            // B range of a segment is cut into nsplit pieces (grid.y)
   uint32_t m, mcap;           // top-m; mcap = m rounded up to 16
   int exclude_same_id;        // leaf mode: skip j == i (hcnng_index.h:153)
+  uint32_t exact;             // exact float order: one sequential accumulator per (A row, B row)
   uint64_t* partial;          // [total A rows][nsplit][m] keys
   const uint32_t* tile_seg;   // [grid.x] segment of each A tile
   const uint32_t* tile_a0;    // [grid.x] first A row (global index) of each tile
@@ -151,6 +152,20 @@ __global__ void __launch_bounds__(256) dense_topk_kernel(DenseArgs A) {
 #pragma unroll
         for (int rb = 0; rb < DT_RB; rb++)
           b[rb] = make_qreg<DT>(*reinterpret_cast<const uint4*>(Bt + (size_t)(lane + 64 * rb) * DT_BSTRIDE + c * 16));
+        if constexpr (is_float_dt<DT>()) {
+          if (A.exact) {      // validation mode: strictly left-to-right, unfused (s.y stays 0)
+            uint4 braw[DT_RB];
+#pragma unroll
+            for (int rb = 0; rb < DT_RB; rb++) braw[rb] = *reinterpret_cast<const uint4*>(Bt + (size_t)(lane + 64 * rb) * DT_BSTRIDE + c * 16);
+#pragma unroll
+            for (int a = 0; a < DT_AW; a++) {
+              const uint4 q = *reinterpret_cast<const uint4*>(At + (size_t)(wave * DT_AW + a) * DT_SEG + c * 16);
+#pragma unroll
+              for (int rb = 0; rb < DT_RB; rb++) { float t = acc[a][rb].s.x; dist_accum_exact<DT, METRIC>(t, q, braw[rb]); acc[a][rb].s.x = t; }
+            }
+            continue;
+          }
+        }
 #pragma unroll
         for (int a = 0; a < DT_AW; a++) {
           const uint4 q = *reinterpret_cast<const uint4*>(At + (size_t)(wave * DT_AW + a) * DT_SEG + c * 16);
@@ -384,7 +399,7 @@ int dense_topk_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, const u
   A.points = ix.points; A.pstride = ix.pstride; A.dbytes = ix.dbytes;
   A.a_ext = d_a_ext; A.a_stride = a_stride; A.a_ids = d_a_ids; A.b_ids = d_b_ids;
   A.a_off = d_a_off; A.b_off = d_b_off; A.na = na; A.nb = nb; A.nsplit = nsplit; A.m = m; A.mcap = mcap;
-  A.exclude_same_id = exclude_same; A.partial = (uint64_t*)ws.buf; A.tile_seg = d_tile_seg; A.tile_a0 = d_tile_a0;
+  A.exclude_same_id = exclude_same; A.exact = ix.exact; A.partial = (uint64_t*)ws.buf; A.tile_seg = d_tile_seg; A.tile_a0 = d_tile_a0;
   const size_t lds = dense_lds_bytes(mcap);
   const dim3 grid(ntiles, nsplit);
 #define CALL_DENSE(DT, MT)                                                                              \
@@ -399,6 +414,8 @@ int dense_topk_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, const u
   else if (ix.dtype == PANN_I8) CALL_DENSE(PANN_I8, PANN_MIPS);
   else if (ix.dtype == PANN_F32 && ix.metric == PANN_L2) CALL_DENSE(PANN_F32, PANN_L2);
   else if (ix.dtype == PANN_F32) CALL_DENSE(PANN_F32, PANN_MIPS);
+  else if (ix.exact && ix.metric == PANN_L2) CALL_DENSE(PANN_F16, PANN_L2);      // exact order: VALU path, not MFMA
+  else if (ix.exact) CALL_DENSE(PANN_F16, PANN_MIPS);
   else {
     const size_t lds2 = (size_t)(DT_A + DT_B) * DT_BSTRIDE + (DT_A + DT_B) * 8 + (size_t)DT_A * mcap * 8;
 #define CALL_MFMA(MT)                                                                                   \
@@ -451,7 +468,7 @@ int query_distances_dev(const DeviceIndex& ix, hipStream_t st, const uint8_t* d_
                         const uint32_t* d_q_ids, uint64_t nq, const uint32_t* d_ids, uint64_t m, int paired,
                         float* d_out) {
   if (nq == 0) return PANN_OK;
-  const PointsView pv{ix.points, ix.pstride, ix.nch};
+  const PointsView pv{ix.points, ix.pstride, ix.nch, ix.exact};
   const size_t qb = ix.nch == 1 ? 0 : (size_t)ix.nch * ix.lpc * 16;
 #define CALL_QD(DT, MT, L, N1) hipLaunchKernelGGL((query_distances_kernel<DT, MT, L, N1>), dim3((uint32_t)nq), dim3(PANN_WAVE), qb, st, pv, ix.dbytes, d_q_ext, q_stride, d_q_ids, d_ids, m, paired, d_out)
   PANN_TYPE_SWITCH(ix, CALL_QD);
@@ -493,7 +510,7 @@ int pivot_split_dev(const DeviceIndex& ix, hipStream_t st, const uint32_t* d_ids
                     const uint64_t* d_tile_lo, const uint32_t* d_tile_cnt, uint32_t ntiles, const uint32_t* d_pa,
                     const uint32_t* d_pb, uint8_t* d_side) {
   if (ntiles == 0) return PANN_OK;
-  const PointsView pv{ix.points, ix.pstride, ix.nch};
+  const PointsView pv{ix.points, ix.pstride, ix.nch, ix.exact};
   const size_t qb = ix.nch == 1 ? 0 : (size_t)ix.nch * ix.lpc * 16;
 #define CALL_PS(DT, MT, L, N1) hipLaunchKernelGGL((pivot_split_kernel<DT, MT, L, N1>), dim3(ntiles), dim3(PANN_WAVE), qb, st, pv, ix.dbytes, d_ids, d_tile_seg, d_tile_lo, d_tile_cnt, d_pa, d_pb, d_side)
   PANN_TYPE_SWITCH(ix, CALL_PS);
@@ -545,7 +562,7 @@ int rerank_dev(const DeviceIndex& ix, hipStream_t st, const uint8_t* d_q, uint64
                float* d_out_dists) {
   if (nq == 0) return PANN_OK;
   if (c == 0 || c > 4096) { set_error("pann_rerank: candidates per query must be in [1,4096]"); return PANN_ERR_BAD_ARG; }
-  const PointsView pv{ix.points, ix.pstride, ix.nch};
+  const PointsView pv{ix.points, ix.pstride, ix.nch, ix.exact};
   const size_t lds = (size_t)((c + 1) & ~1u) * 8 + (ix.nch == 1 ? 0 : (size_t)ix.nch * ix.lpc * 16);
 #define CALL_RR(DT, MT, L, N1) hipLaunchKernelGGL((rerank_kernel<DT, MT, L, N1>), dim3((uint32_t)nq), dim3(PANN_WAVE), lds, st, pv, ix.dbytes, d_q, q_stride, d_cand, c, d_cnt, k, resort, d_out_ids, d_out_dists)
   PANN_TYPE_SWITCH(ix, CALL_RR);

@@ -253,7 +253,7 @@ int hcnng_build_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, uint32
   if (mst_deg > 255) { set_error("pann_hcnng_build: mst_deg > 255"); return PANN_ERR_BAD_ARG; }
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto secs = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
-  const PointsView pv{ix.points, ix.pstride, ix.nch};
+  const PointsView pv{ix.points, ix.pstride, ix.nch, ix.exact};
   const size_t qb = ix.nch == 1 ? 0 : (size_t)ix.nch * ix.lpc * 16;
   const uint32_t nb256 = (uint32_t)((n + 255) / 256);
 

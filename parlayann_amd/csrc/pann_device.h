@@ -225,11 +225,56 @@ __device__ __forceinline__ uint4 load16_guarded(const uint8_t* row, uint32_t off
 // 16 B per chunk, so one load instruction covers 64/LPC whole row segments; U candidates-groups
 // are in flight per lane before the first use.  emit(has, ci, id, dist) is called by ALL lanes
 // (uniform control flow); `has` is true on the first lane of each candidate group. ----
-struct PointsView { const uint8_t* points; uint32_t pstride; uint32_t nch; };
+struct PointsView { const uint8_t* points; uint32_t pstride; uint32_t nch; uint32_t exact; };
+
+// "Exact float order" (debug / validation mode, float element types only): one LANE per candidate sums
+// the whole row strictly left to right with one rounding per subtract, multiply and add -- the reference's
+// scalar loop (euclidian_point.h:83-90, mips_point.h:59-65) -- so results on REAL-valued data are
+// bit-identical to the CPU path.  The zero padding adds (0-0)^2 = +0 terms, which change nothing.
+template <int DT, int METRIC>
+__device__ __forceinline__ void dist_accum_exact(float& acc, const uint4& a, const uint4& q) {
+#pragma clang fp contract(off)
+  if constexpr (DT == PANN_F32) {
+    const float av[4] = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w)};
+    const float qv[4] = {__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w)};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if constexpr (METRIC == PANN_L2) { const float t = qv[i] - av[i]; const float p = t * t; acc = acc + p; }
+      else { const float p = qv[i] * av[i]; acc = acc + p; }
+    }
+  } else if constexpr (DT == PANN_F16) {
+    half8 ah, qh;
+    __builtin_memcpy(&ah, &a, 16);
+    __builtin_memcpy(&qh, &q, 16);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const float af = (float)ah[i], qf = (float)qh[i];
+      if constexpr (METRIC == PANN_L2) { const float t = qf - af; const float p = t * t; acc = acc + p; }
+      else { const float p = qf * af; acc = acc + p; }
+    }
+  }
+}
+template <int DT> constexpr bool is_float_dt() { return DT == PANN_F32 || DT == PANN_F16; }
+
 
 template <int DT, int METRIC, int LPC, bool NCH1, int U, typename Emit>
 __device__ __forceinline__ void gather_tile(const PointsView& PV, const QReg<DT>& qreg, const uint4* qlds,
                                             const uint32_t* Pl, uint32_t m, int lane, Emit&& emit) {
+  if constexpr (is_float_dt<DT>() && !NCH1) {
+    if (PV.exact) {      // lane-per-candidate, sequential sum (the whole query sits in qlds in this mode)
+      const uint32_t nchunks = PV.pstride / 16;
+      for (uint32_t s0 = 0; s0 < m; s0 += PANN_WAVE) {
+        const uint32_t ci = s0 + lane;
+        const uint32_t id = Pl[min(ci, m - 1)];
+        const uint8_t* row = PV.points + (uint64_t)id * PV.pstride;
+        float acc = 0.0f;
+        for (uint32_t ch = 0; ch < nchunks; ch++)
+          dist_accum_exact<DT, METRIC>(acc, *reinterpret_cast<const uint4*>(row + ch * 16), qlds[ch]);
+        emit(ci < m, ci, id, METRIC == PANN_MIPS ? -acc : acc);
+      }
+      return;
+    }
+  }
   constexpr int G = PANN_WAVE / LPC;
   const int grp = lane / LPC, sub = lane % LPC;
   for (uint32_t s0 = 0; s0 < m; s0 += G * U) {

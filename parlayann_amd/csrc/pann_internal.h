@@ -27,6 +27,7 @@ struct DeviceIndex {
   uint32_t pstride = 0;  // device row stride in bytes
   uint32_t lpc = 0;      // lanes per candidate in the gather-distance loops (4,8,16,32)
   uint32_t nch = 0;      // 16-byte chunks per lane: pstride = nch*lpc*16
+  uint32_t exact = 0;    // exact float order (validation mode): lane-per-candidate sequential sums; forces lpc=4
   uint32_t max_deg = 0;
   uint32_t gstride = 0;  // uint32 per graph row on the device
 };

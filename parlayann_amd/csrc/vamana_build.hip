@@ -458,7 +458,7 @@ int robust_prune_batch_host(const DeviceIndex& ix, Workspace& ws, hipStream_t st
   PANN_HIP(hipMemcpyAsync(d_seg, h_seg.data(), m * 4, hipMemcpyHostToDevice, st));
   PANN_HIP(hipMemsetAsync(d_dc, 0, m * 4, st));
   PruneArgs pa{};
-  pa.pv = PointsView{ix.points, ix.pstride, ix.nch}; pa.dbytes = ix.dbytes;
+  pa.pv = PointsView{ix.points, ix.pstride, ix.nch, ix.exact}; pa.dbytes = ix.dbytes;
   pa.graph = ix.graph; pa.gstride = ix.gstride; pa.max_deg = ix.max_deg;
   pa.owners = d_own; pa.cand_ids = d_cid; pa.cand_dists = cand_dists ? d_cd : nullptr;
   pa.cand_base = d_base; pa.cand_cnt = d_cnt; pa.seg_begin = d_seg; pa.seg_end = d_send;
@@ -543,7 +543,7 @@ int insert_batch_dev(const DeviceIndex& ix, Workspace& ws, Workspace& ws2, Works
     hipLaunchKernelGGL(fixed_stride_setup_kernel, dim3((m + 255) / 256), dim3(256), 0, st, d_base, d_seg, m, vcap, seg_stride);
     PANN_HIP(hipMemsetAsync(d_dc, 0, (size_t)m * 4, st));
     PruneArgs pa{};
-    pa.pv = PointsView{ix.points, ix.pstride, ix.nch}; pa.dbytes = ix.dbytes;
+    pa.pv = PointsView{ix.points, ix.pstride, ix.nch, ix.exact}; pa.dbytes = ix.dbytes;
     pa.graph = ix.graph; pa.gstride = ix.gstride; pa.max_deg = ix.max_deg;
     pa.owners = d_batch; pa.cand_ids = d_vis_ids; pa.cand_dists = d_vis_d; pa.cand_base = d_base; pa.cand_cnt = d_vis_cnt;
     pa.seg_begin = d_seg; pa.seg_end = d_send; pa.dcmps = d_dc; pa.add_out_nbrs = 1; pa.m = m;
@@ -641,7 +641,7 @@ int insert_batch_dev(const DeviceIndex& ix, Workspace& ws, Workspace& ws2, Works
 
 int sort_neighbors_dev(const DeviceIndex& ix, hipStream_t st) {
   if (ix.max_deg > 4096) { set_error("sort_neighbors: max_deg > 4096"); return PANN_ERR_UNSUPPORTED; }
-  const PointsView pv{ix.points, ix.pstride, ix.nch};
+  const PointsView pv{ix.points, ix.pstride, ix.nch, ix.exact};
   const size_t qb = query_lds_bytes(ix);
 #define CALL_SORT(DT, MT, L, N1) hipLaunchKernelGGL((sort_rows_kernel<DT, MT, L, N1>), dim3((uint32_t)ix.n), dim3(PANN_WAVE), qb, st, pv, ix.dbytes, ix.graph, ix.gstride, (uint32_t)ix.n)
   PANN_TYPE_SWITCH(ix, CALL_SORT);

@@ -45,7 +45,7 @@ def host_graph(n, max_deg):
 
 
 class DeviceIndex:
-    def __init__(self, points, graph=None, max_degree=None, metric="Euclidian", device=0):
+    def __init__(self, points, graph=None, max_degree=None, metric="Euclidian", device=0, exact_float_order=False):
         lib = _capi.load()
         points = np.ascontiguousarray(points)
         if points.ndim != 2 or points.dtype not in _DT:
@@ -64,6 +64,8 @@ class DeviceIndex:
         check(lib.pann_index_create(C.byref(h), _ptr(points), n, d, _DT[points.dtype], _row_stride(points),
                                     self.metric, _ptr(graph), self.max_degree, device))
         self._h, self._lib = h, lib
+        if exact_float_order:      # validation mode: bit-identical float results on real-valued data
+            check(lib.pann_index_set_exact_float_order(h, 1))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -160,6 +162,12 @@ class DeviceIndex:
         return st
 
     # ---- distances / dense all-pairs ----
+    def hcnng_build(self, num_clusters, cluster_size, mst_deg, seed=1):
+        """hcnng_index.h:273-281 on the device (trees, leaf kNN, Kruskal); returns {tree_s, leaf_knn_s, mst_s}."""
+        times = np.zeros(3, np.float64)
+        check(self._lib.pann_hcnng_build(self._h, num_clusters, cluster_size, mst_deg, seed, _ptr(times)))
+        return {"tree_s": times[0], "leaf_knn_s": times[1], "mst_s": times[2]}
+
     def pair_distances(self, a_ids, b_ids):
         a = np.ascontiguousarray(a_ids, dtype=np.uint32); b = np.ascontiguousarray(b_ids, dtype=np.uint32)
         out = np.empty(len(a), np.float32)

@@ -85,12 +85,9 @@ def hcnng_build(X, metric, num_clusters, cluster_size, mst_deg, seed=1, device=0
     X = np.ascontiguousarray(X)
     if not host_mirror:
         ix = DeviceIndex(X, max_degree=num_clusters * mst_deg, metric=metric, device=device)
-        times = np.zeros(3, np.float64)
-        _capi.check(ix._lib.pann_hcnng_build(ix.handle, num_clusters, cluster_size, mst_deg, seed,
-                                             times.ctypes.data_as(C.c_void_p)))
+        hcnng_build.last_times = ix.hcnng_build(num_clusters, cluster_size, mst_deg, seed)
         G = ix.get_graph()
         ix.close()
-        hcnng_build.last_times = {"tree_s": times[0], "leaf_knn_s": times[1], "mst_s": times[2]}
         return G
     n, d = X.shape
     maxdeg = num_clusters * mst_deg                      # BuildParams::max_degree (types.h:210-214)
