@@ -214,6 +214,20 @@ int pann_leaf_knn_batch(pann_index* idx, const uint32_t* ids, const uint64_t* le
 int pann_pivot_split(pann_index* idx, const uint32_t* ids, const uint64_t* seg_offsets, uint64_t nseg,
                      const uint32_t* pivot_a, const uint32_t* pivot_b, uint8_t* out_side);
 
+/* BFS range search -- range_search (algorithms/utils/beamSearch.h:245-306; caller vamana/neighbors.h:88-101).
+ * Per query: every start that is not the query's own vertex and lies within radius_2 seeds `result`
+ * (:271-277); then result[position++] is expanded breadth first: neighbours not yet seen (an EXACT set,
+ * :256) and not the query's own vertex are remembered, cost one distance comparison each and join `result`
+ * iff dist <= radius_2 (:280-297).  Exactly one of queries / query_ids is given (a base-point query skips
+ * its own vertex, Point::same_as).  starts is nstarts ids (shared) or nq x nstarts (starts_per_query != 0);
+ * 0xFFFFFFFF entries are padding.  out_ids is nq x max_results in BFS order, out_counts[i] <= max_results;
+ * a query whose result would exceed max_results stops there and sets out_truncated[i] = 1.
+ * out_dist_cmps / out_truncated may be NULL.  (The reference's first radius argument is unused, :250.) */
+int pann_range_search(pann_index* idx, const void* queries, const uint32_t* query_ids, uint64_t nq,
+                      uint64_t q_stride_bytes, const uint32_t* starts, uint32_t nstarts, int starts_per_query,
+                      float radius_2, uint32_t max_results, uint32_t* out_ids, uint32_t* out_counts,
+                      uint32_t* out_dist_cmps, uint32_t* out_truncated);
+
 /* Whole HCNNG build_index (hcnng_index.h:273-281) on the device: for each of num_clusters trees the
  * random two-pivot cluster tree (clusterEdge.h:99-144; level-synchronous: split kernel, prefix scan,
  * stable scatter), the all-pairs 10-NN of every leaf (hcnng_index.h:145-181), the per-leaf

@@ -24,6 +24,7 @@
 #include <limits>
 #include <thread>
 #include <utility>
+#include <unordered_set>
 #include <vector>
 #include <chrono>
 
@@ -541,6 +542,61 @@ int pann_oracle_leaf_knn(const void* points, uint64_t n, uint32_t d, int dtype, 
       out_ids[i * m + j] = j < kk ? v[j].id : 0xFFFFFFFFu;
       out_dists[i * m + j] = j < kk ? v[j].dist : std::numeric_limits<float>::infinity();
     }
+  });
+  return 0;
+}
+
+// beamSearch.h:245-306 range_search: starts within radius_2 seed `result` (:271-277), then a BFS over
+// result[position++] (:280-297) with an exact `seen` set; same_as(p) (:272,287) holds only when the query is
+// base point `self` (pointer equality, euclidian_point.h:178-180).  Rows of out_ids have capacity cap; a
+// longer result is cut there and flagged (the product does the same; the reference's vector is unbounded).
+int pann_oracle_range_search(const void* points, uint64_t n, uint32_t d, int dtype, uint64_t stride, int metric,
+                             const uint32_t* graph, uint32_t maxdeg, const void* queries, uint64_t q_stride,
+                             const uint32_t* query_ids, uint64_t nq, const uint32_t* starts, uint32_t nstarts,
+                             int starts_per_query, float radius_2, uint32_t cap, uint32_t* out_ids,
+                             uint32_t* out_counts, uint32_t* out_cmps, uint32_t* out_trunc, int nthreads) {
+  Dataset D{(const uint8_t*)points, n, d, dtype, stride, metric, graph, maxdeg};
+  parallel_for(0, nq, nthreads, [&](size_t qi) {
+    const void* q = query_ids ? D.row(query_ids[qi]) : (const void*)((const uint8_t*)queries + qi * q_stride);
+    const int64_t self = query_ids ? (int64_t)query_ids[qi] : -1;
+    std::vector<uint32_t> result;
+    std::unordered_set<uint32_t> seen;
+    long cmps = 0;
+    bool trunc = false;
+    const uint32_t* sp = starts + (starts_per_query ? qi * nstarts : 0);
+    for (uint32_t j = 0; j < nstarts && !trunc; j++) {
+      const uint32_t v = sp[j];
+      if (v == 0xFFFFFFFFu) continue;                                   // padding (not in the reference)
+      if (seen.count(v) > 0 || (int64_t)v == self) continue;
+      cmps++;
+      if (D.dist(q, v) > radius_2) continue;
+      if (result.size() == cap) { trunc = true; break; }
+      result.push_back(v);
+      seen.insert(v);
+    }
+    size_t position = 0;
+    while (position < result.size() && !trunc) {
+      const uint32_t next = result[position++];
+      const uint32_t* row = D.grow(next);
+      std::vector<uint32_t> unseen;
+      for (uint32_t i = 0; i < row[0]; i++) {
+        const uint32_t v = row[1 + i];
+        if (seen.count(v) > 0 || (int64_t)v == self) continue;
+        unseen.push_back(v);
+        seen.insert(v);
+      }
+      for (uint32_t v : unseen) {
+        cmps++;
+        if (D.dist(q, v) <= radius_2) {
+          if (result.size() == cap) { trunc = true; continue; }
+          result.push_back(v);
+        }
+      }
+    }
+    for (size_t j = 0; j < result.size(); j++) out_ids[qi * cap + j] = result[j];
+    out_counts[qi] = (uint32_t)result.size();
+    if (out_cmps) out_cmps[qi] = (uint32_t)cmps;
+    if (out_trunc) out_trunc[qi] = trunc ? 1u : 0u;
   });
   return 0;
 }

@@ -60,6 +60,8 @@ SIGNATURES = {
     "pann_index_max_degree": (C.c_uint32, [C.c_void_p]),
     "pann_index_device": (C.c_int, [C.c_void_p]),
     "pann_index_set_exact_float_order": (C.c_int, [C.c_void_p, C.c_int]),
+    "pann_range_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32,
+                                    C.c_int, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pann_index_set_graph": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pann_index_update_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "pann_index_get_graph": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -675,6 +675,47 @@ int pann_rerank(pann_index* idx, const void* queries, uint64_t nq, uint64_t q_st
 }
 
 
+int pann_range_search(pann_index* idx, const void* queries, const uint32_t* query_ids, uint64_t nq,
+                      uint64_t q_stride_bytes, const uint32_t* starts, uint32_t nstarts, int starts_per_query,
+                      float radius_2, uint32_t max_results, uint32_t* out_ids, uint32_t* out_counts,
+                      uint32_t* out_dist_cmps, uint32_t* out_truncated) {
+  if (int rc = check_idx(idx, "pann_range_search")) return rc;
+  if (nq == 0) return PANN_OK;
+  const DeviceIndex& ix = idx->ix;
+  if ((queries == nullptr) == (query_ids == nullptr)) { set_error("pann_range_search: exactly one of queries / query_ids must be given"); return PANN_ERR_BAD_ARG; }
+  if (!starts || nstarts == 0 || !out_ids || !out_counts || max_results == 0) { set_error("pann_range_search: null or empty argument"); return PANN_ERR_BAD_ARG; }
+  if (queries && q_stride_bytes < ix.dbytes) { set_error("pann_range_search: query stride smaller than a row"); return PANN_ERR_BAD_ARG; }
+  if (query_ids)
+    for (uint64_t i = 0; i < nq; i++)
+      if (query_ids[i] >= ix.n) { set_error("pann_range_search: query id out of range"); return PANN_ERR_BAD_ARG; }
+  const uint64_t ns_total = (starts_per_query ? nq : 1) * (uint64_t)nstarts;
+  for (uint64_t i = 0; i < ns_total; i++)
+    if (starts[i] != SENTINEL && starts[i] >= ix.n) { set_error("pann_range_search: start id out of range"); return PANN_ERR_BAD_ARG; }
+  DeviceGuard g(idx->device);
+  hipStream_t st = idx->stream;
+  const size_t qbytes = queries ? nq * q_stride_bytes + 16 : nq * 4;
+  if (int rc = idx->stage[2].ensure(qbytes)) return rc;
+  if (int rc = idx->stage[3].ensure(ns_total * 4)) return rc;
+  if (int rc = idx->stage[4].ensure(nq * (uint64_t)max_results * 4)) return rc;
+  if (int rc = idx->stage[5].ensure(nq * 4)) return rc;
+  if (int rc = idx->stage[6].ensure(nq * 4)) return rc;
+  if (int rc = idx->stage[7].ensure(nq * 4)) return rc;
+  if (queries) PANN_HIP(hipMemcpyAsync(idx->stage[2].p, queries, (nq - 1) * q_stride_bytes + ix.dbytes, hipMemcpyHostToDevice, st));
+  else PANN_HIP(hipMemcpyAsync(idx->stage[2].p, query_ids, nq * 4, hipMemcpyHostToDevice, st));
+  PANN_HIP(hipMemcpyAsync(idx->stage[3].p, starts, ns_total * 4, hipMemcpyHostToDevice, st));
+  if (int rc = range_search_dev(ix, idx->ws, st, queries ? idx->stage[2].as<uint8_t>() : nullptr, q_stride_bytes,
+                                queries ? nullptr : idx->stage[2].as<uint32_t>(), nq, idx->stage[3].as<uint32_t>(), nstarts,
+                                starts_per_query, radius_2, max_results, idx->stage[4].as<uint32_t>(),
+                                idx->stage[5].as<uint32_t>(), idx->stage[6].as<uint32_t>(), idx->stage[7].as<uint32_t>())) return rc;
+  PANN_HIP(hipMemcpyAsync(out_ids, idx->stage[4].p, nq * (uint64_t)max_results * 4, hipMemcpyDeviceToHost, st));
+  PANN_HIP(hipMemcpyAsync(out_counts, idx->stage[5].p, nq * 4, hipMemcpyDeviceToHost, st));
+  if (out_dist_cmps) PANN_HIP(hipMemcpyAsync(out_dist_cmps, idx->stage[6].p, nq * 4, hipMemcpyDeviceToHost, st));
+  if (out_truncated) PANN_HIP(hipMemcpyAsync(out_truncated, idx->stage[7].p, nq * 4, hipMemcpyDeviceToHost, st));
+  PANN_HIP(hipStreamSynchronize(st));
+  return PANN_OK;
+}
+
+
 int pann_hcnng_build(pann_index* idx, uint32_t num_clusters, uint32_t cluster_size, uint32_t mst_deg, uint64_t seed,
                      double* times3) {
   if (int rc = check_idx(idx, "pann_hcnng_build")) return rc;

@@ -86,6 +86,12 @@ int rerank_dev(const DeviceIndex& ix, hipStream_t st, const uint8_t* d_q, uint64
                const uint32_t* d_cand, uint32_t c, const uint32_t* d_cnt, uint32_t k, int resort, uint32_t* d_out_ids,
                float* d_out_dists);
 
+// range_search.hip
+int range_search_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, const uint8_t* d_q, uint64_t q_stride,
+                     const uint32_t* d_qids, uint64_t nq, const uint32_t* d_starts, uint32_t nstarts,
+                     int starts_per_query, float radius_2, uint32_t cap, uint32_t* d_out_ids, uint32_t* d_out_counts,
+                     uint32_t* d_out_cmps, uint32_t* d_out_trunc);
+
 // hcnng_build.hip
 int hcnng_build_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, uint32_t num_clusters, uint32_t cluster_size,
                     uint32_t mst_deg, uint64_t seed, double* times3);

@@ -1,5 +1,6 @@
 // beam_search.h -- host mirror of the batched / single-query search surface of
-// algorithms/utils/beamSearch.h: beam_search (:217-241), searchAll (:353-387), qsearchAll (:537-565).
+// algorithms/utils/beamSearch.h: beam_search (:217-241), range_search (:245-306), searchAll (:353-387),
+// qsearchAll (:537-565).
 // Each call is ONE pann_batch_search over the whole batch (the parallel_for seam :374/:556).
 #pragma once
 #include <utility>
@@ -98,6 +99,40 @@ std::vector<std::vector<indexType>> qsearchAll(PointRange& Query_Points, DeviceI
                                                const QueryParams& QP) {
   QueryParams q = QP;
   return searchAll<PointRange, indexType>(Query_Points, DI, QueryStats, starting_point, q);
+}
+
+// range_search(p, G, Points, starting_points, radius, radius_2, QP) -> (result in BFS order, distance comparisons)
+// (:245-306).  `self` = the query's own vertex when p is a base point (Point::same_as is pointer equality), else -1.
+// One pann_range_search; the result row grows until it is not truncated.
+template <class PointRange, typename indexType>
+std::pair<std::vector<indexType>, long> range_search(const typename PointRange::Point p, DeviceIndex<PointRange, indexType>& DI,
+                                                     const std::vector<indexType>& starting_points, float /*radius: unused, :250*/,
+                                                     float radius_2, const QueryParams& /*QP*/, long self = -1) {
+  if (starting_points.empty()) return {std::vector<indexType>(), 0L};
+  for (uint32_t cap = 1024;; cap *= 8) {
+    std::vector<uint32_t> ids(cap);
+    uint32_t cnt = 0, cmps = 0, trunc = 0;
+    const uint32_t qid = (uint32_t)self;
+    pann_check(pann_range_search(DI.h, self < 0 ? p.values : nullptr, self < 0 ? nullptr : &qid, 1, (uint64_t)p.params.num_bytes(),
+                                 starting_points.data(), (uint32_t)starting_points.size(), 0, radius_2, cap, ids.data(), &cnt,
+                                 &cmps, &trunc));
+    if (trunc && cap < (1u << 30)) continue;
+    ids.resize(cnt);
+    return {std::vector<indexType>(ids.begin(), ids.end()), (long)cmps};
+  }
+}
+
+// the loop of vamana/neighbors.h:95-101 as ONE launch: base point i searches from starts[i] (a row of nstarts ids,
+// 0xFFFFFFFF = padding); returns (counts, distance comparisons) per point
+template <class PointRange, typename indexType>
+std::pair<std::vector<long>, std::vector<long>> self_range_search(DeviceIndex<PointRange, indexType>& DI, size_t n,
+                                                                  const std::vector<uint32_t>& starts, uint32_t nstarts,
+                                                                  float radius_2, uint32_t max_results = 1024) {
+  std::vector<uint32_t> qid(n), ids(n * (size_t)max_results), cnt(n), cmps(n), trunc(n);
+  for (size_t i = 0; i < n; i++) qid[i] = (uint32_t)i;
+  pann_check(pann_range_search(DI.h, nullptr, qid.data(), n, 0, starts.data(), nstarts, 1, radius_2, max_results, ids.data(),
+                               cnt.data(), cmps.data(), trunc.data()));
+  return {std::vector<long>(cnt.begin(), cnt.end()), std::vector<long>(cmps.begin(), cmps.end())};
 }
 
 }  // namespace parlayANN

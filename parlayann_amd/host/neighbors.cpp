@@ -3,6 +3,7 @@
 // (check_nn_recall.h:221-226) and prints recall / QPS.  Flags: -base_path -query_path -gt_path
 // -graph_path -graph_outfile -data_type {uint8,int8,float} -dist_func {Euclidian,mips} -k -Q -R -L
 // -alpha -num_passes -cluster_size -mst_deg -num_clusters -alg {vamana,hcnng} -device -seed -device_build {1,0}
+// -self 1 -range 1 -radius -radius_2 [-use_existing 1]  (vamana/neighbors.h:86-104)
 #include <cstring>
 #include <map>
 #include <string>
@@ -61,6 +62,29 @@ int run(const Args& a) {
     DeviceIndex<PR, indexType> DI(Points, &G, 0, (int)a.num("-device", 0));
     QueryParams QP(k, Q, 1.35, (long)G.size(), (long)G.max_degree());   // check_nn_recall.h:219,224
     for (int rep = 0; rep < 5; rep++) checkRecall<PR, indexType>(DI, Queries, GT, 0, k, QP, true);   // :221-226
+  } else if (a.num("-self", 0) && a.num("-range", 0)) {
+    // vamana/neighbors.h:86-104: every base point range-searches from its own vertex.  same_as() skips that
+    // start, so upstream reports 0 edges here; `-use_existing 1` seeds with the point's out-neighbours instead
+    // (the commented branch beamSearch.h:260-262)
+    const float radius = (float)a.flt("-radius", 0.0), radius_2 = (float)a.flt("-radius_2", 0.0);
+    std::cout << "radius = " << radius << " radius_2 = " << radius_2 << std::endl;
+    DeviceIndex<PR, indexType> DI(Points, &G, 0, (int)a.num("-device", 0));
+    const size_t n = Points.size();
+    const bool existing = a.num("-use_existing", 0) != 0;
+    const uint32_t ns = existing ? (uint32_t)G.max_degree() : 1;
+    std::vector<uint32_t> starts(n * (size_t)ns, 0xFFFFFFFFu);
+    for (size_t i = 0; i < n; i++) {
+      if (!existing) { starts[i] = (uint32_t)i; continue; }
+      auto row = G[(indexType)i];
+      for (size_t j = 0; j < row.size(); j++) starts[i * ns + j] = row[(indexType)j];
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    auto [counts, cmps] = self_range_search<PR, indexType>(DI, n, starts, ns, radius_2);
+    std::cout << "range search time: " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << std::endl;
+    long edges = 0, dc = 0;
+    for (size_t i = 0; i < n; i++) { edges += counts[i]; dc += cmps[i]; }
+    std::cout << "edges within range: " << edges << std::endl;
+    std::cout << "distance comparisons during range = " << dc << std::endl;
   }
   return 0;
 }

@@ -168,6 +168,27 @@ class DeviceIndex:
         check(self._lib.pann_hcnng_build(self._h, num_clusters, cluster_size, mst_deg, seed, _ptr(times)))
         return {"tree_s": times[0], "leaf_knn_s": times[1], "mst_s": times[2]}
 
+    def range_search(self, starts, radius_2, max_results, queries=None, query_ids=None):
+        """beamSearch.h:245-306: BFS from the starts that lie within radius_2 over all vertices within radius_2.
+        starts: (ns,) shared or (nq, ns) per query, 0xFFFFFFFF = padding.  Rows of `ids` are in BFS order."""
+        starts = np.ascontiguousarray(starts, dtype=np.uint32)
+        per_query = starts.ndim == 2
+        if (queries is None) == (query_ids is None):
+            raise ValueError("exactly one of queries / query_ids must be given")
+        if queries is not None:
+            q = np.ascontiguousarray(queries); nq = len(q); qp, qs, qi = _ptr(q), _row_stride(q), None
+        else:
+            qid = np.ascontiguousarray(query_ids, dtype=np.uint32); nq = len(qid); qp, qs, qi = None, 0, _ptr(qid)
+        if per_query and len(starts) != nq:
+            raise ValueError("per-query starts must have one row per query")
+        ids = np.full((nq, max_results), 0xFFFFFFFF, np.uint32)
+        cnt = np.zeros(nq, np.uint32); cmps = np.zeros(nq, np.uint32); trunc = np.zeros(nq, np.uint32)
+        check(self._lib.pann_range_search(self._h, qp, qi, nq, qs, _ptr(starts), starts.shape[-1], 1 if per_query else 0,
+                                          float(radius_2), max_results, _ptr(ids), _ptr(cnt), _ptr(cmps), _ptr(trunc)))
+        for i in range(nq):
+            ids[i, cnt[i]:] = 0xFFFFFFFF
+        return {"ids": ids, "counts": cnt, "dist_cmps": cmps, "truncated": trunc}
+
     def pair_distances(self, a_ids, b_ids):
         a = np.ascontiguousarray(a_ids, dtype=np.uint32); b = np.ascontiguousarray(b_ids, dtype=np.uint32)
         out = np.empty(len(a), np.float32)

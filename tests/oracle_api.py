@@ -165,6 +165,27 @@ class Oracle:
         assert rc == 0
         return oi, od
 
+    def range_search(self, points, graph, starts, radius_2, cap, queries=None, query_ids=None, metric="l2", threads=None):
+        points = np.ascontiguousarray(points); graph = np.ascontiguousarray(graph, dtype=np.uint32)
+        n, d = points.shape
+        starts = np.ascontiguousarray(starts, dtype=np.uint32)
+        per_query = starts.ndim == 2
+        if queries is not None:
+            queries = np.ascontiguousarray(queries); nq = len(queries)
+        else:
+            query_ids = np.ascontiguousarray(query_ids, dtype=np.uint32); nq = len(query_ids)
+        ids = np.full((nq, cap), 0xFFFFFFFF, np.uint32)
+        cnt = np.zeros(nq, np.uint32); cmps = np.zeros(nq, np.uint32); trunc = np.zeros(nq, np.uint32)
+        rc = self.lib.pann_oracle_range_search(
+            _p(points), C.c_uint64(n), C.c_uint32(d), C.c_int(DT[points.dtype]), C.c_uint64(points.strides[0]),
+            C.c_int(_m(metric)), _p(graph), C.c_uint32(graph.shape[1] - 1),
+            _p(queries) if queries is not None else None, C.c_uint64(queries.strides[0] if queries is not None else 0),
+            _p(query_ids) if query_ids is not None else None, C.c_uint64(nq), _p(starts), C.c_uint32(starts.shape[-1]),
+            C.c_int(1 if per_query else 0), C.c_float(radius_2), C.c_uint32(cap), _p(ids), _p(cnt), _p(cmps), _p(trunc),
+            C.c_int(threads or self.threads))
+        assert rc == 0
+        return {"ids": ids, "counts": cnt, "dist_cmps": cmps, "truncated": trunc}
+
     def recall(self, result_ids, gt_ids, gt_dists, k):
         r = np.ascontiguousarray(result_ids, dtype=np.uint32)
         g = np.ascontiguousarray(gt_ids, dtype=np.uint32); gd = np.ascontiguousarray(gt_dists, dtype=np.float32)

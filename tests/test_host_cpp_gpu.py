@@ -82,6 +82,26 @@ def test_hcnng_cli_graph_quality(exe, files):
     np.testing.assert_array_equal(G, io.read_graph(d / "h3.graph"))
 
 
+def test_cli_self_range_search(exe, files, oracle):
+    """-self 1 -range 1 (vamana/neighbors.h:86-104): the upstream call starts each point at its own vertex, which
+    same_as() skips -> 0 edges; -use_existing 1 seeds with the out-neighbours and must agree with the oracle."""
+    d, X, Q, gt, gd = files
+    _run(exe, "-base_path", d / "base.bin", "-graph_outfile", d / "r.graph", "-data_type", "uint8", "-R", 32, "-L", 64, "-seed", 5)
+    G = io.read_graph(d / "r.graph")
+    r2 = float(np.median(oracle.bruteforce_knn(X, X[:200], 6)[1][:, -1]))
+    out = _run(exe, "-base_path", d / "base.bin", "-graph_path", d / "r.graph", "-data_type", "uint8", "-self", 1, "-range", 1,
+               "-radius_2", r2)
+    assert "edges within range: 0" in out and "distance comparisons during range = 0" in out
+    out = _run(exe, "-base_path", d / "base.bin", "-graph_path", d / "r.graph", "-data_type", "uint8", "-self", 1, "-range", 1,
+               "-radius_2", r2, "-use_existing", 1)
+    st = np.full((len(X), G.shape[1] - 1), 0xFFFFFFFF, np.uint32)
+    cols = np.arange(G.shape[1] - 1)[None, :]
+    st[cols < G[:, :1]] = G[:, 1:][cols < G[:, :1]]
+    o = oracle.range_search(X, G, st, r2, 1024, query_ids=np.arange(len(X), dtype=np.uint32))
+    assert int(re.findall(r"edges within range: ([0-9]+)", out)[0]) == int(o["counts"].sum()) > 0
+    assert int(re.findall(r"comparisons during range = ([0-9]+)", out)[0]) == int(o["dist_cmps"].sum())
+
+
 def test_pivot_split_matches_oracle_distances(oracle):
     X = datasets.sift_like(3000, 96, seed=1, dtype=np.float32)
     ix = DeviceIndex(X, max_degree=8)
