@@ -161,7 +161,7 @@ def main():
             "build_s": build_s,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "beam_search_b64_kernel" if args.beam <= 64 else "beam_search_kernel", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                         "kernel": "beam_search_b64_kernel" if args.beam <= 64 else ("beam_search_b128_kernel" if args.beam <= 128 else "beam_search_kernel"), "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(ix, Xf, Q.astype(np.float32), args)

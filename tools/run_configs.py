@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Run the BASELINE.json configurations that fit one GPU (C1, C3, C5) end to end on the device and
 print one JSON line each (build time, recall, QPS, counters).  Not a bench contract: the numbers go
-to DESIGN.md.  usage: run_configs.py [c1] [c3[:n]] [c5[:n]]"""
+to DESIGN.md.  usage: run_configs.py [c1] [quickstart] [c3[:n]] [c5[:n]] [c4shard[:n]]"""
 import json
 import os
 import sys
@@ -23,6 +23,55 @@ def search_stats(ix, Q, k, beam, reps=3):
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     return r, len(Q) / best
+
+
+def device_qps(ix, Q, k, beam, cut=1.35, reps=5):
+    """device-resident timing like bench.py: queries already in HBM, HIP events around pann_batch_search_dev"""
+    import ctypes as C
+    import torch
+    from parlayann_amd import _capi
+    from parlayann_amd._capi import QueryParams, SearchOut, check
+    lib = _capi.load()
+    dev = torch.device("cuda", 0)
+    nq = len(Q)
+    d_q = torch.from_numpy(np.ascontiguousarray(Q).view(np.uint8).reshape(nq, -1)).to(dev)
+    d_s = torch.zeros(1, dtype=torch.int32, device=dev)
+    d_ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    d_vis = torch.empty(nq, dtype=torch.int32, device=dev); d_cm = torch.empty(nq, dtype=torch.int32, device=dev)
+    qp = QueryParams(k=k, beam=beam, cut=cut, limit=ix.n, degree_limit=ix.max_degree, rerank_factor=100, pad=1.0)
+    out = SearchOut(ids=d_ids.data_ptr(), dists=None, out_k=k, frontier_size=None, visited_count=d_vis.data_ptr(),
+                    dist_cmps=d_cm.data_ptr(), degree_sum=None, visited_ids=None, visited_dists=None, visited_cap=0)
+    st = torch.cuda.current_stream(dev)
+    best = None
+    for _ in range(reps + 1):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(st)
+        check(lib.pann_batch_search_dev(ix.handle, d_q.data_ptr(), None, nq, Q.shape[1] * Q.itemsize, d_s.data_ptr(), 1,
+                                        C.byref(qp), C.byref(out), C.c_void_p(st.cuda_stream)))
+        b.record(st); torch.cuda.synchronize(dev)
+        ms = a.elapsed_time(b)
+        best = ms if best is None else min(best, ms)
+    return d_ids.cpu().numpy().view(np.uint32), float(d_vis.float().mean()), float(d_cm.float().mean()), nq / (best / 1e3)
+
+
+def quickstart():
+    """the shape of docs/quickstart.md:37-101 (the only published numbers): 100K x 128 f32, Vamana R=32 L=64 a=1.2
+    one pass, 10K queries, 10@10 at the beam widths of the published table (synthetic SIFT-shaped data)"""
+    X = datasets.sift1m_like(100_000, 128, seed=1234, dtype=np.float32)
+    Q = datasets.sift1m_like(10_000, 128, seed=4321, dtype=np.float32)
+    ix = DeviceIndex(X, max_degree=32)
+    ix.vamana_build(32, 64, 1.2, num_passes=1, seed=2)            # warm-up build (allocations, code load)
+    t0 = time.time(); st = ix.vamana_build(32, 64, 1.2, num_passes=1, seed=1); tb = time.time() - t0
+    G = ix.get_graph()
+    gt, gd = ix.bruteforce_knn(Q, 100)
+    out = {"config": "quickstart shape: 100K x 128 f32 Vamana R=32 L=64 a=1.2 x1, 10K queries (published: build 0.8123 s on 72 cores)",
+           "build_s": tb, "build_phases_s": {"search": st.t_search_s, "prune": st.t_prune_s, "bidirect": st.t_bidirect_s,
+                                             "reprune": st.t_reprune_s},
+           "avg_visited_per_insert": st.visited_total / 1e5, "avg_degree": float(G[:, 0].mean()), "max_degree": int(G[:, 0].max())}
+    for beam, cut in ((12, 1.35), (17, 1.35), (45, 1.35), (70, 1.35), (1000, 10.0)):
+        ids, vis, cm, qps = device_qps(ix, Q, 10, beam, cut)
+        out[f"Q{beam}"] = {"recall": recall_at_k(ids, gt, gd, 10), "visited": vis, "cmps": cm, "qps_device_resident": qps}
+    print(json.dumps(out), flush=True)
 
 
 def c1():
@@ -101,6 +150,8 @@ if __name__ == "__main__":
         name, _, arg = a.partition(":")
         if name == "c1":
             c1()
+        elif name == "quickstart":
+            quickstart()
         elif name == "c3":
             c3(int(arg or 10_000_000))
         elif name == "c5":
