@@ -16,6 +16,8 @@ except Exception:  # torch is plumbing, not a requirement of the C-ABI
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpann.so")
+if os.environ.get("PANN_LIBRARY"):      # A/B runs of diagnostic builds (tools/): same ABI, another file
+    LIB_PATH = os.environ["PANN_LIBRARY"]
 
 PANN_U8, PANN_I8, PANN_F32, PANN_F16 = 0, 1, 2, 3
 PANN_L2, PANN_MIPS = 0, 1

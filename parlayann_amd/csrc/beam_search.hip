@@ -34,6 +34,11 @@ namespace pann {
 #ifndef PANN_GU
 #define PANN_GU 4   /* candidate groups in flight per lane in the main gather */
 #endif
+#ifndef PANN_GU_B128
+/* beam 65..128: the 16 KB filter limits a CU to 8 queries; a whole adjacency row per memory round trip
+   (16 groups in flight) was measured SLOWER than 4 (C3 build search phase 1.50 s vs 1.19 s) */
+#define PANN_GU_B128(LPC) 4
+#endif
 #ifndef PANN_MINWAVES
 #define PANN_MINWAVES 1
 #endif
@@ -104,14 +109,29 @@ __device__ __forceinline__ uint32_t lower_bound_lds(const uint64_t* A, uint32_t 
 // lane i is a hit iff the LAST earlier lane with the same slot holds the same id, or, when there is
 // none, iff the table held a_i on entry.  Returns "seen" per lane and leaves the table as the
 // sequential loop would.
+// Lanes that share a slot are found by writing the lane number somewhere slot-indexed and reading it
+// back: into the table itself when it lives in LDS; into a 1 KB LDS scratch T (index = slot mod 1024,
+// false sharing only costs a loop trip) when the table lives in HBM, which then sees ONE dependent
+// load (the entry values) and one fire-and-forget store per call instead of four round trips.
 template <bool HASH_LDS>
-__device__ __forceinline__ bool filter_update(uint32_t* H, uint32_t hmask, bool active, uint32_t a, int lane) {
+__device__ __forceinline__ bool filter_update(uint32_t* H, uint32_t hmask, bool active, uint32_t a, int lane,
+                                              uint8_t* T = nullptr) {
   const uint32_t s = (uint32_t)hash64_2((uint64_t)a) & hmask;
-  uint32_t old = active ? hload<HASH_LDS>(H, s) : 0u;
-  hsync<HASH_LDS>();
-  if (active) hstore<HASH_LDS>(H, s, (uint32_t)lane);   // some lane of each slot group wins
-  hsync<HASH_LDS>();
-  uint32_t w = active ? hload<HASH_LDS>(H, s) : (uint32_t)lane;
+  uint32_t old, w;
+  if constexpr (HASH_LDS) {
+    old = active ? H[s] : 0u;
+    __syncthreads();
+    if (active) H[s] = (uint32_t)lane;                   // some lane of each slot group wins
+    __syncthreads();
+    w = active ? H[s] : (uint32_t)lane;
+  } else {
+    __builtin_amdgcn_s_waitcnt(0);                       // the previous call's table stores have been acknowledged
+    old = active ? __hip_atomic_load(H + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    const uint32_t t = s & 1023u;
+    if (active) T[t] = (uint8_t)lane;
+    __syncthreads();
+    w = active ? (uint32_t)T[t] : (uint32_t)lane;
+  }
   uint64_t losers = __ballot(active && w != (uint32_t)lane);
   int prev = -1;       // last earlier lane with my slot
   bool last = true;    // no later lane with my slot
@@ -128,9 +148,14 @@ __device__ __forceinline__ bool filter_update(uint32_t* H, uint32_t hmask, bool 
   }
   const uint32_t a_prev = __shfl(a, prev < 0 ? lane : prev);
   const bool seen = active && (prev >= 0 ? (a_prev == a) : (old == a));
-  hsync<HASH_LDS>();
-  if (active && last) hstore<HASH_LDS>(H, s, a);
-  hsync<HASH_LDS>();
+  if constexpr (HASH_LDS) {
+    __syncthreads();
+    if (active && last) H[s] = a;
+    __syncthreads();
+  } else {
+    if (active && last) __hip_atomic_store(H + s, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();                                     // T may be rewritten by the next call
+  }
   return seen;
 }
 
@@ -172,7 +197,7 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES) beam_search_kernel(B
   uint8_t* NFv = Fv + P.bcap;                            // [bcap]
   uint16_t* CP = reinterpret_cast<uint16_t*>(NFv + P.bcap);  // [ccap] candidate's lower_bound in F
   uint4* qlds = reinterpret_cast<uint4*>(CP + P.ccap);   // [nch*LPC] query (generic variant)
-  uint32_t* Hl = reinterpret_cast<uint32_t*>(qlds + (NCH1 ? 0 : P.nch * LPC));  // [1<<bits] if HASH_LDS
+  uint32_t* Hl = reinterpret_cast<uint32_t*>(qlds + (NCH1 ? 0 : P.nch * LPC));  // [1<<bits] if HASH_LDS, else 1 KB replay scratch
 #define PANN_PL (reinterpret_cast<uint32_t*>(NF))        /* [64] filter survivors of one row chunk */
 
   const uint32_t hsize = 1u << P.bits, hmask = hsize - 1u;
@@ -215,7 +240,7 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES) beam_search_kernel(B
       const uint32_t i = s0 + lane;
       const bool act = i < P.nstarts;
       const uint32_t a = act ? P.starts[(size_t)qi * P.starts_stride + i] : 0u;
-      (void)filter_update<HASH_LDS>(H, hmask, act, a, lane);
+      (void)filter_update<HASH_LDS>(H, hmask, act, a, lane, reinterpret_cast<uint8_t*>(Hl));
       if (act) PANN_PL[lane] = a;
       __syncthreads();
       const uint32_t m = min(P.nstarts - s0, (uint32_t)PANN_WAVE);
@@ -270,7 +295,7 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES) beam_search_kernel(B
           PANN_STAMP(1);   // adjacency row arrived
           if (am == 0ull) break;
           degsum += __popcll(am);
-          const bool seen = filter_update<HASH_LDS>(H, hmask, act, a, lane);
+          const bool seen = filter_update<HASH_LDS>(H, hmask, act, a, lane, reinterpret_cast<uint8_t*>(Hl));
           const bool keep = act && !seen && ((int64_t)a != self);     // :133
           const uint64_t km = __ballot(keep);
           const uint32_t m = __popcll(km);
@@ -615,7 +640,7 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES_B64) beam_search_b64_
 // per lane (entry e lives in lane e % 64, slot e / 64).  LDS per query: the 16 KB filter + a 128-entry
 // scatter scratch + candidates = 18.2 KB -> 9 queries per CU (the LDS-frontier kernel needs 19.9 KB).
 // =============================================================================================
-template <int DT, int METRIC, int LPC, bool NCH1>
+template <int DT, int METRIC, int LPC, bool NCH1, bool HASH_LDS>
 __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P) {
   constexpr int RB = 2;
   const int lane = threadIdx.x;
@@ -624,25 +649,38 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
   uint64_t* C = S + 64 * RB;                                // [ccap] candidates (unsorted)
   uint8_t* Sv = reinterpret_cast<uint8_t*>(C + P.ccap);     // [128] flags of the scatter scratch
   uint4* qlds = reinterpret_cast<uint4*>(Sv + 64 * RB);     // [nch*LPC] query (generic variant)
-  uint32_t* H = reinterpret_cast<uint32_t*>(qlds + (NCH1 ? 0 : P.nch * LPC));  // [1<<bits]
+  uint32_t* Hl = reinterpret_cast<uint32_t*>(qlds + (NCH1 ? 0 : P.nch * LPC));  // [1<<bits] if HASH_LDS, else 1 KB replay scratch
+  uint8_t* T = reinterpret_cast<uint8_t*>(Hl);
   uint32_t* Pl = reinterpret_cast<uint32_t*>(S);
 
   const uint32_t hsize = 1u << P.bits, hmask = hsize - 1u;
   const uint32_t beam = P.beam;
   const uint32_t BIG_ORD = f2ord(2147483648.0f);
-  const uint32_t qi = blockIdx.x;
-
-  for (uint32_t i = lane; i < hsize; i += PANN_WAVE) H[i] = SENTINEL;
+  // filter in LDS: one query per block.  Filter in HBM (16 KB of LDS would cap a CU at 8 queries): persistent
+  // blocks, one table per block, queries pulled from a counter.
+  uint32_t qi = blockIdx.x;
+  if constexpr (!HASH_LDS) {
+    qi = 0;
+    if (lane == 0) qi = atomicAdd(P.work_counter, 1u);
+    qi = __builtin_amdgcn_readfirstlane(qi);
+  }
+  while (qi < P.nq) {
+  uint32_t* H = HASH_LDS ? Hl : P.hash_global + ((size_t)blockIdx.x << P.bits);
+  for (uint32_t i = lane; i < hsize; i += PANN_WAVE) hstore<HASH_LDS>(H, i, SENTINEL);
   const int64_t self = P.query_ids ? (int64_t)P.query_ids[qi] : -1;
   const uint8_t* qrow = P.query_ids ? P.points + (uint64_t)self * P.pstride : P.queries + (uint64_t)qi * P.qstride;
   QReg<DT> qreg{};
   load_query<DT, LPC, NCH1>(qrow, P.dbytes, P.nch, qreg, qlds, lane);
-  __syncthreads();
+  hsync<HASH_LDS>();
 
   uint32_t f = 0, c = 0, nvis = 0, dcmps = P.nstarts, degsum = 0, ndrop = 0;
   uint64_t fkey[RB] = {KEY_INF, KEY_INF};
   uint32_t fflag[RB] = {0, 0};
   uint64_t* DL = P.dropped + (size_t)qi * P.dcap;
+#ifdef PANN_STAMPS
+  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
   auto entry_key = [&](uint32_t e) -> uint64_t {            // uniform e
     return (e < 64) ? readlane64(fkey[0], (int)e) : readlane64(fkey[1], (int)e - 64);
   };
@@ -650,7 +688,7 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
   {   // start points (:66-70); nstarts <= 64 in this kernel
     const bool act = lane < (int)P.nstarts;
     const uint32_t a = act ? P.starts[(size_t)qi * P.starts_stride + lane] : 0u;
-    (void)filter_update<true>(H, hmask, act, a, lane);
+    (void)filter_update<HASH_LDS>(H, hmask, act, a, lane, T);
     if (act) Pl[lane] = a;
     __syncthreads();
     c = gather_distances<DT, METRIC, LPC, NCH1, 4>(P, qreg, qlds, Pl, P.nstarts, 0xFFFFFFFFu, C, c, lane);
@@ -666,6 +704,7 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
       if ((um0 | um1) == 0ull || nvis >= P.limit) break;
       const int cur_idx = um0 ? __ffsll((unsigned long long)um0) - 1 : 64 + __ffsll((unsigned long long)um1) - 1;
       const bool more_unvisited = (__popcll(um0) + __popcll(um1)) > 1;          // offset + 1 < remain (:165)
+      PANN_STAMP(0);
       const uint64_t cur_key = entry_key((uint32_t)cur_idx);
       const uint32_t cur = key_id(cur_key);
       if (cur_idx < 64) { if (lane == cur_idx) fflag[0] = 1; } else { if (lane == cur_idx - 64) fflag[1] = 1; }
@@ -688,17 +727,20 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
         if (i < P.gstride) a = row[i];
         const bool act = (a != SENTINEL) && (i < P.degree_limit);
         const uint64_t am = __ballot(act);
+        PANN_STAMP(1);
         if (am == 0ull) break;
         degsum += __popcll(am);
-        const bool seen = filter_update<true>(H, hmask, act, a, lane);
+        const bool seen = filter_update<HASH_LDS>(H, hmask, act, a, lane, T);
         const bool keep = act && !seen && ((int64_t)a != self);
         const uint64_t km = __ballot(keep);
         const uint32_t m = __popcll(km);
         if (keep) Pl[lanes_below(km, lane)] = a;
         dcmps += m;
         __syncthreads();
-        if (m) c = gather_distances<DT, METRIC, LPC, NCH1, PANN_GU>(P, qreg, qlds, Pl, m, cutoff_ord, C, c, lane);
+        PANN_STAMP(2);
+        if (m) c = gather_distances<DT, METRIC, LPC, NCH1, PANN_GU_B128(LPC)>(P, qreg, qlds, Pl, m, cutoff_ord, C, c, lane);
         __syncthreads();
+        PANN_STAMP(3);
       }
       const bool skip = (c == 0) || (P.skip_enabled && c < beam / 8 && more_unvisited);
       do_merge = !skip;
@@ -790,8 +832,12 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
       for (int r = 0; r < RB; r++) if (lane + 64 * r >= (int)f) { fkey[r] = KEY_INF; fflag[r] = 0u; }
       c = 0;
     }
+    PANN_STAMP(4);
     first = false;
   }
+#ifdef PANN_STAMPS
+  if (lane == 0 && P.stamps) for (int i = 0; i < 8; i++) P.stamps[(size_t)qi * 8 + i] = stamp_sum[i];
+#endif
 
   const size_t qo = (size_t)qi * P.out.out_k;
 #pragma unroll
@@ -809,6 +855,14 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
     if (P.out.dist_cmps) P.out.dist_cmps[qi] = dcmps;
     if (P.out.degree_sum) P.out.degree_sum[qi] = degsum;
   }
+  if constexpr (HASH_LDS) {
+    break;
+  } else {
+    __syncthreads();
+    if (lane == 0) qi = atomicAdd(P.work_counter, 1u);
+    qi = __builtin_amdgcn_readfirstlane(qi);
+  }
+  }   // while (qi < P.nq)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -824,6 +878,7 @@ void choose_point_layout(uint32_t dbytes, uint32_t* lpc, uint32_t* nch) {
   if (r64 == 256) { *lpc = 16; *nch = 1; return; }
   if (r64 == 512) { *lpc = 32; *nch = 1; return; }
   if (r64 % 256 == 0) { *lpc = 16; *nch = r64 / 256; return; }
+  if (r64 % 128 == 0) { *lpc = 8; *nch = r64 / 128; return; }      // e.g. f32 d=96: 384 B = 3 chunks of 8 lanes x 16 B
   *lpc = 4; *nch = r64 / 64;
 }
 
@@ -835,6 +890,7 @@ static uint32_t filter_bits(int64_t beam) {  // :52
 
 struct Plan {
   uint32_t bits, bcap, ccap, deg_eff, dcap, lds_bytes; bool hash_lds; uint32_t slots; bool b64; bool b128;
+  bool b128_hbm;   // beam 65..128 with the filter in HBM (persistent blocks)
 };
 
 static Plan make_plan(const DeviceIndex& ix, const SearchArgs& a) {
@@ -852,7 +908,7 @@ static Plan make_plan(const DeviceIndex& ix, const SearchArgs& a) {
                  (size_t)p.ccap * 2 + (nch1 ? 0 : (size_t)ix.nch * ix.lpc * 16);
   size_t hbytes = (size_t)4 << p.bits;
   p.hash_lds = (hbytes <= 16384) && (fixed + hbytes <= 64 * 1024);
-  p.lds_bytes = (uint32_t)(fixed + (p.hash_lds ? hbytes : 0));
+  p.lds_bytes = (uint32_t)(fixed + (p.hash_lds ? hbytes : 1024));      // HBM filter: 1 KB replay scratch (filter_update)
   p.slots = 256 * 8;
   p.b64 = p.hash_lds && p.bcap == 64;
   if (p.b64) {   // register-frontier kernel: scratch[64] + candidates (exact, 8-entry granules) + flags + query + filter
@@ -860,8 +916,16 @@ static Plan make_plan(const DeviceIndex& ix, const SearchArgs& a) {
     p.lds_bytes = (uint32_t)(64 * 8 + (size_t)p.ccap * 8 + 64 + (nch1 ? 0 : (size_t)ix.nch * ix.lpc * 16) + hbytes);
   }
   p.b128 = p.hash_lds && p.bcap == 128 && a.nstarts <= 64;
+  p.b128_hbm = false;
   if (p.b128) {
     p.ccap = (std::max<uint32_t>(beam / 8 + p.deg_eff, a.nstarts) + 7) / 8 * 8;
+    // 16 KB of filter per query leaves 8 queries per CU (2 048 on the chip).  Larger batches put the table in HBM
+    // (Infinity-Cache resident): one dependent load per adjacency row, 3x the queries per CU; measured +17 % on the
+    // C3 build's search phase and +10 % on beam-128 queries -- the 64 single-word table requests per row make the
+    // L2 request rate the new limit (in-kernel stamps: every phase 2-3x longer at 3x the occupancy).
+    static const bool force_lds = getenv("PANN_B128_LDS") != nullptr;       // diagnostic A/B switch
+    p.b128_hbm = (hbytes > 8192) && a.nq > 2048 && !force_lds;
+    if (p.b128_hbm) { p.hash_lds = false; hbytes = 1024; p.slots = 256 * 32; }   // one table per block, >= the resident waves
     p.lds_bytes = (uint32_t)(128 * 8 + (size_t)p.ccap * 8 + 128 + (nch1 ? 0 : (size_t)ix.nch * ix.lpc * 16) + hbytes);
   }
   return p;
@@ -881,8 +945,14 @@ static hipError_t launch_variant(const BSParams& P, const Plan& p, hipStream_t s
     auto kern = beam_search_b64_kernel<DT, METRIC, LPC, NCH1>;
     hipLaunchKernelGGL(kern, dim3(P.nq), dim3(PANN_WAVE), p.lds_bytes, stream, P);
   } else if (p.b128) {   // two frontier entries per lane
-    auto kern = beam_search_b128_kernel<DT, METRIC, LPC, NCH1>;
-    hipLaunchKernelGGL(kern, dim3(P.nq), dim3(PANN_WAVE), p.lds_bytes, stream, P);
+    if (p.b128_hbm) {
+      auto kern = beam_search_b128_kernel<DT, METRIC, LPC, NCH1, false>;
+      const uint32_t grid = (uint32_t)std::min<uint64_t>(P.nq, p.slots);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(PANN_WAVE), p.lds_bytes, stream, P);
+    } else {
+      auto kern = beam_search_b128_kernel<DT, METRIC, LPC, NCH1, true>;
+      hipLaunchKernelGGL(kern, dim3(P.nq), dim3(PANN_WAVE), p.lds_bytes, stream, P);
+    }
   } else if (p.hash_lds) {
     auto kern = beam_search_kernel<DT, METRIC, LPC, NCH1, true>;
     if (p.lds_bytes > 48 * 1024)
@@ -906,6 +976,7 @@ static hipError_t launch_layout(const DeviceIndex& ix, const BSParams& P, const 
     if (ix.lpc == 32) return launch_variant<DT, METRIC, 32, true>(P, p, s);
   }
   if (ix.lpc == 4) return launch_variant<DT, METRIC, 4, false>(P, p, s);
+  if (ix.lpc == 8) return launch_variant<DT, METRIC, 8, false>(P, p, s);
   if (ix.lpc == 16) return launch_variant<DT, METRIC, 16, false>(P, p, s);
   return hipErrorInvalidValue;
 }

@@ -257,7 +257,7 @@ __device__ __forceinline__ void dist_accum_exact(float& acc, const uint4& a, con
 template <int DT> constexpr bool is_float_dt() { return DT == PANN_F32 || DT == PANN_F16; }
 
 
-template <int DT, int METRIC, int LPC, bool NCH1, int U, typename Emit>
+template <int DT, int METRIC, int LPC, bool NCH1, int U_, typename Emit>
 __device__ __forceinline__ void gather_tile(const PointsView& PV, const QReg<DT>& qreg, const uint4* qlds,
                                             const uint32_t* Pl, uint32_t m, int lane, Emit&& emit) {
   if constexpr (is_float_dt<DT>() && !NCH1) {
@@ -276,6 +276,7 @@ __device__ __forceinline__ void gather_tile(const PointsView& PV, const QReg<DT>
     }
   }
   constexpr int G = PANN_WAVE / LPC;
+  constexpr int U = NCH1 ? U_ : (U_ > 1 ? U_ / 2 : 1);      // multi-chunk rows keep CB x U loads in flight per lane
   const int grp = lane / LPC, sub = lane % LPC;
   for (uint32_t s0 = 0; s0 < m; s0 += G * U) {
     Acc<DT> acc[U];
@@ -291,16 +292,31 @@ __device__ __forceinline__ void gather_tile(const PointsView& PV, const QReg<DT>
 #pragma unroll
       for (int u = 0; u < U; u++) { acc[u].clear(); dist_accum<DT, METRIC>(acc[u], v[u], qreg); }
     } else {
+      // rows of several chunks per lane: CB chunks of every group are requested before the first is used, so a
+      // row costs ceil(nch/CB) memory round trips instead of nch; a batch running past the row re-reads its last
+      // chunk (a cache hit) and skips the arithmetic (wave-uniform branch)
+      constexpr int CB = 3;
 #pragma unroll
       for (int u = 0; u < U; u++) acc[u].clear();
-      for (uint32_t ch = 0; ch < PV.nch; ch++) {
-        uint4 v[U];
-        const QReg<DT> qv = make_qreg<DT>(qlds[ch * LPC + sub]);
+      const uint8_t* rp[U];
 #pragma unroll
-        for (int u = 0; u < U; u++)
-          v[u] = *reinterpret_cast<const uint4*>(PV.points + (uint64_t)ids[u] * PV.pstride + (ch * LPC + sub) * 16);
+      for (int u = 0; u < U; u++) rp[u] = PV.points + (uint64_t)ids[u] * PV.pstride + sub * 16;
+      for (uint32_t ch0 = 0; ch0 < PV.nch; ch0 += CB) {
+        uint4 v[CB][U];
 #pragma unroll
-        for (int u = 0; u < U; u++) dist_accum<DT, METRIC>(acc[u], v[u], qv);
+        for (int cb = 0; cb < CB; cb++) {
+          const uint32_t chx = min(ch0 + cb, PV.nch - 1);
+#pragma unroll
+          for (int u = 0; u < U; u++) v[cb][u] = *reinterpret_cast<const uint4*>(rp[u] + chx * (LPC * 16));
+        }
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++) {
+          if (ch0 + cb < PV.nch) {
+            const QReg<DT> qv = make_qreg<DT>(qlds[(ch0 + cb) * LPC + sub]);
+#pragma unroll
+            for (int u = 0; u < U; u++) dist_accum<DT, METRIC>(acc[u], v[cb][u], qv);
+          }
+        }
       }
     }
 #pragma unroll
@@ -344,6 +360,7 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t m, int lane) {
     else if ((ix).nch == 1 && (ix).lpc == 16) { CALL(DT, MT, 16, true); }       \
     else if ((ix).nch == 1 && (ix).lpc == 32) { CALL(DT, MT, 32, true); }       \
     else if ((ix).lpc == 4) { CALL(DT, MT, 4, false); }                         \
+    else if ((ix).lpc == 8) { CALL(DT, MT, 8, false); }                         \
     else { CALL(DT, MT, 16, false); }                                           \
   } while (0)
 #define PANN_TYPE_SWITCH(ix, CALL)                                                             \
