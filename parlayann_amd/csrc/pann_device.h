@@ -257,6 +257,76 @@ __device__ __forceinline__ void dist_accum_exact(float& acc, const uint4& a, con
 template <int DT> constexpr bool is_float_dt() { return DT == PANN_F32 || DT == PANN_F16; }
 
 
+// one iteration of the gather: U groups of G = 64/LPC candidates starting at Pl[s0]
+template <int DT, int METRIC, int LPC, bool NCH1, int U, typename Emit>
+__device__ __forceinline__ void gather_iter(const PointsView& PV, const QReg<DT>& qreg, const uint4* qlds,
+                                            const uint32_t* Pl, uint32_t m, uint32_t s0, int lane, Emit&& emit) {
+  constexpr int G = PANN_WAVE / LPC;
+  const int grp = lane / LPC, sub = lane % LPC;
+  Acc<DT> acc[U];
+  uint32_t ids[U];
+  // groups past the end re-read the last candidate (a cache hit) instead of branching around the load
+#pragma unroll
+  for (int u = 0; u < U; u++) ids[u] = Pl[min(s0 + u * G + grp, m - 1)];
+  if constexpr (NCH1) {
+    uint4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+      v[u] = *reinterpret_cast<const uint4*>(PV.points + (uint64_t)ids[u] * PV.pstride + sub * 16);
+#pragma unroll
+    for (int u = 0; u < U; u++) { acc[u].clear(); dist_accum<DT, METRIC>(acc[u], v[u], qreg); }
+  } else {
+    // rows of several chunks per lane: CB chunks of every group are requested before the first is used, so a
+    // row costs ceil(nch/CB) memory round trips instead of nch; a batch running past the row re-reads its last
+    // chunk (a cache hit) and skips the arithmetic (wave-uniform branch)
+    constexpr int CB = 3;
+#pragma unroll
+    for (int u = 0; u < U; u++) acc[u].clear();
+    const uint8_t* rp[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) rp[u] = PV.points + (uint64_t)ids[u] * PV.pstride + sub * 16;
+    for (uint32_t ch0 = 0; ch0 < PV.nch; ch0 += CB) {
+      uint4 v[CB][U];
+#pragma unroll
+      for (int cb = 0; cb < CB; cb++) {
+        const uint32_t chx = min(ch0 + cb, PV.nch - 1);
+#pragma unroll
+        for (int u = 0; u < U; u++) v[cb][u] = *reinterpret_cast<const uint4*>(rp[u] + chx * (LPC * 16));
+      }
+#pragma unroll
+      for (int cb = 0; cb < CB; cb++) {
+        if (ch0 + cb < PV.nch) {
+          const QReg<DT> qv = make_qreg<DT>(qlds[(ch0 + cb) * LPC + sub]);
+#pragma unroll
+          for (int u = 0; u < U; u++) dist_accum<DT, METRIC>(acc[u], v[cb][u], qv);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const auto tot = group_sum<LPC>(acc_lane_value<DT, METRIC>(acc[u]));
+    const float dist = dist_finish<DT, METRIC>(tot);
+    const uint32_t ci = s0 + u * G + grp;
+    emit((sub == 0) && (ci < m), ci, ids[u], dist);
+  }
+}
+
+// the last, partial iteration: as few groups as cover the remaining candidates (the kernels are bound by
+// instructions issued per candidate slot, so idle groups are not free)
+template <int DT, int METRIC, int LPC, bool NCH1, int U, typename Emit>
+__device__ __forceinline__ void gather_span(const PointsView& PV, const QReg<DT>& qreg, const uint4* qlds,
+                                            const uint32_t* Pl, uint32_t m, uint32_t s0, int lane, Emit&& emit) {
+  constexpr int G = PANN_WAVE / LPC;
+  if constexpr (U > 1) {
+    if (m - s0 <= (uint32_t)(G * (U / 2))) {
+      gather_span<DT, METRIC, LPC, NCH1, U / 2>(PV, qreg, qlds, Pl, m, s0, lane, emit);
+      return;
+    }
+  }
+  gather_iter<DT, METRIC, LPC, NCH1, U>(PV, qreg, qlds, Pl, m, s0, lane, emit);
+}
+
 template <int DT, int METRIC, int LPC, bool NCH1, int U_, typename Emit>
 __device__ __forceinline__ void gather_tile(const PointsView& PV, const QReg<DT>& qreg, const uint4* qlds,
                                             const uint32_t* Pl, uint32_t m, int lane, Emit&& emit) {
@@ -277,56 +347,9 @@ __device__ __forceinline__ void gather_tile(const PointsView& PV, const QReg<DT>
   }
   constexpr int G = PANN_WAVE / LPC;
   constexpr int U = NCH1 ? U_ : (U_ > 1 ? U_ / 2 : 1);      // multi-chunk rows keep CB x U loads in flight per lane
-  const int grp = lane / LPC, sub = lane % LPC;
-  for (uint32_t s0 = 0; s0 < m; s0 += G * U) {
-    Acc<DT> acc[U];
-    uint32_t ids[U];
-    // groups past the end re-read the last candidate (a cache hit) instead of branching around the load
-#pragma unroll
-    for (int u = 0; u < U; u++) ids[u] = Pl[min(s0 + u * G + grp, m - 1)];
-    if constexpr (NCH1) {
-      uint4 v[U];
-#pragma unroll
-      for (int u = 0; u < U; u++)
-        v[u] = *reinterpret_cast<const uint4*>(PV.points + (uint64_t)ids[u] * PV.pstride + sub * 16);
-#pragma unroll
-      for (int u = 0; u < U; u++) { acc[u].clear(); dist_accum<DT, METRIC>(acc[u], v[u], qreg); }
-    } else {
-      // rows of several chunks per lane: CB chunks of every group are requested before the first is used, so a
-      // row costs ceil(nch/CB) memory round trips instead of nch; a batch running past the row re-reads its last
-      // chunk (a cache hit) and skips the arithmetic (wave-uniform branch)
-      constexpr int CB = 3;
-#pragma unroll
-      for (int u = 0; u < U; u++) acc[u].clear();
-      const uint8_t* rp[U];
-#pragma unroll
-      for (int u = 0; u < U; u++) rp[u] = PV.points + (uint64_t)ids[u] * PV.pstride + sub * 16;
-      for (uint32_t ch0 = 0; ch0 < PV.nch; ch0 += CB) {
-        uint4 v[CB][U];
-#pragma unroll
-        for (int cb = 0; cb < CB; cb++) {
-          const uint32_t chx = min(ch0 + cb, PV.nch - 1);
-#pragma unroll
-          for (int u = 0; u < U; u++) v[cb][u] = *reinterpret_cast<const uint4*>(rp[u] + chx * (LPC * 16));
-        }
-#pragma unroll
-        for (int cb = 0; cb < CB; cb++) {
-          if (ch0 + cb < PV.nch) {
-            const QReg<DT> qv = make_qreg<DT>(qlds[(ch0 + cb) * LPC + sub]);
-#pragma unroll
-            for (int u = 0; u < U; u++) dist_accum<DT, METRIC>(acc[u], v[cb][u], qv);
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const auto tot = group_sum<LPC>(acc_lane_value<DT, METRIC>(acc[u]));
-      const float dist = dist_finish<DT, METRIC>(tot);
-      const uint32_t ci = s0 + u * G + grp;
-      emit((sub == 0) && (ci < m), ci, ids[u], dist);
-    }
-  }
+  uint32_t s0 = 0;
+  for (; s0 + G * U <= m; s0 += G * U) gather_iter<DT, METRIC, LPC, NCH1, U>(PV, qreg, qlds, Pl, m, s0, lane, emit);
+  if (s0 < m) gather_span<DT, METRIC, LPC, NCH1, U>(PV, qreg, qlds, Pl, m, s0, lane, emit);
 }
 
 // load one row (device layout, or an external query row of `valid` bytes) as the wave's query:
