@@ -71,6 +71,35 @@ __device__ __forceinline__ void list_insert(uint64_t* list, uint32_t mcap, uint6
   wave_lds_sync();
 }
 
+// ---- lane-parallel top-m for m <= 16 (the HCNNG leaf case, m = 10) ----
+// The one-insert-at-a-time list above costs ~40 instructions per improving candidate with the whole wave
+// working on ONE row; at m = 10, N = 1000 that was 65 % of the leaf kernel.  Here the wave's 16 A rows are
+// updated together: lane (row = lane & 15, quarter = lane >> 4) keeps its own sorted list of the best keys
+// among the columns {quarter*32 .. quarter*32+31} of every B tile in REGISTERS (16 entries; the unused
+// leading 16-m hold key 0, which no real key displaces, so the m-th best is always entry 15).  Per tile the
+// distances go through LDS (transposed: K[row][column]), each lane marks the entries below its threshold in
+// a 32-bit mask and the marked ones are inserted by an unrolled compare-exchange chain; the four quarter
+// lists of a row are merged by rank once, after the last tile.
+constexpr int TM_KSTRIDE = 133;   // words per K row: 4 quarters x 33 (bank spread)
+
+__device__ __forceinline__ void tm_chain_insert(uint64_t (&L)[16], uint64_t x) {
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const bool lt = x < L[i];
+    const uint64_t lo = lt ? x : L[i], hi = lt ? L[i] : x;
+    L[i] = lo; x = hi;
+  }
+}
+
+// first index in sorted list[0..16) with list[i] >= x
+__device__ __forceinline__ uint32_t tm_lower_bound16(const uint64_t* list, uint64_t x) {
+  uint32_t lo = 0;
+#pragma unroll
+  for (int step = 8; step >= 1; step >>= 1) lo += (list[lo + step - 1] < x) ? step : 0;
+  lo += (list[lo] < x) ? 1 : 0;      // lo <= 15 here
+  return lo;
+}
+
 template <int DT, int METRIC>
 __global__ void __launch_bounds__(256) dense_topk_kernel(DenseArgs A) {
   extern __shared__ __align__(16) uint8_t smem[];
@@ -96,6 +125,11 @@ __global__ void __launch_bounds__(256) dense_topk_kernel(DenseArgs A) {
   for (uint32_t i = tid; i < DT_A * A.mcap; i += 256) lists[i] = KEY_INF;
   if (tid < DT_A) Aid[tid] = (tid < (int)na_tile && A.a_ids) ? A.a_ids[a0 + tid] : SENTINEL;
   __syncthreads();
+  const bool lane_lists = (A.mcap == 16);                 // m <= 16: lane-parallel top-m (uniform)
+  uint64_t TL[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) TL[i] = (i < 16 - (int)A.m) ? 0ull : KEY_INF;
+  uint32_t* Kw = reinterpret_cast<uint32_t*>(Bt) + wave * (DT_AW * TM_KSTRIDE);   // aliases the B tile between tiles
 
   const uint32_t nseg = (A.pstride + DT_SEG - 1) / DT_SEG;
   // stage one 256-byte segment of 64 rows: 16 lanes x 16 B per row, 16 rows per pass of 256 threads
@@ -174,6 +208,38 @@ __global__ void __launch_bounds__(256) dense_topk_kernel(DenseArgs A) {
         }
       }
     }
+    if (lane_lists) {
+      __syncthreads();                                    // every wave is done reading Bt: reuse it as K
+#pragma unroll
+      for (int rb = 0; rb < DT_RB; rb++) {
+        const uint32_t brow = lane + 64 * rb;
+        const uint32_t bid = Bid[brow];
+#pragma unroll
+        for (int a = 0; a < DT_AW; a++) {
+          const uint32_t ar = wave * DT_AW + a;
+          const float dist = dist_finish<DT, METRIC>(acc_lane_value<DT, METRIC>(acc[a][rb]));
+          bool ok = (brow < nb_tile) && (ar < na_tile);
+          if (A.exclude_same_id) ok = ok && (bid != Aid[ar]);
+          Kw[a * TM_KSTRIDE + (brow >> 5) * 33 + (brow & 31)] = ok ? f2ord(dist) : 0xFFFFFFFFu;
+        }
+      }
+      wave_lds_sync();
+      {
+        const uint32_t* krow = Kw + (lane & 15) * TM_KSTRIDE + (lane >> 4) * 33;
+        const uint32_t* idq = Bid + (lane >> 4) * 32;
+        uint64_t tau = TL[15];
+        uint32_t bits = 0;
+#pragma unroll 8
+        for (int j = 0; j < 32; j++) bits |= (krow[j] <= (uint32_t)(tau >> 32) && krow[j] != 0xFFFFFFFFu) ? (1u << j) : 0u;
+        while (bits) {                                    // per-lane walk over its marked entries
+          const int j = __ffs(bits) - 1;
+          bits &= bits - 1;
+          const uint64_t x = ((uint64_t)krow[j] << 32) | idq[j];
+          if (x < tau) { tm_chain_insert(TL, x); tau = TL[15]; }
+        }
+      }
+      continue;                                           // the next tile's barrier protects K
+    }
     // ---- top-m update: wave-private lists of its 16 A rows ----
 #pragma unroll
     for (int rb = 0; rb < DT_RB; rb++) {
@@ -205,6 +271,37 @@ __global__ void __launch_bounds__(256) dense_topk_kernel(DenseArgs A) {
     }
   }
   __syncthreads();
+  if (lane_lists) {
+    // merge the four quarter lists of every row by rank: position in the own list + entries of the other three
+    // that are smaller (keys are unique: a column belongs to one quarter)
+    uint64_t* Lw = reinterpret_cast<uint64_t*>(Bt) + (size_t)wave * (DT_AW * 4 * 16);       // [16 rows][4][16]
+    const int row = lane & 15, qd = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 16; i++) Lw[(row * 4 + qd) * 16 + i] = TL[i];
+    const uint32_t ar = wave * DT_AW + row;
+    uint64_t* out = A.partial + ((a0 + ar) * A.nsplit + blockIdx.y) * A.m;
+    __syncthreads();                                      // lists visible
+    const int lead = 16 - (int)A.m;                       // leading key-0 entries of every list
+    if (ar < na_tile && qd == 0) {                        // slots beyond the number of real keys stay empty
+      int real = 0;
+#pragma unroll
+      for (int o = 0; o < 4; o++) real += (int)tm_lower_bound16(Lw + (row * 4 + o) * 16, KEY_INF) - lead;
+      for (int j = real; j < (int)A.m; j++) out[j] = KEY_INF;
+    }
+    if (ar < na_tile) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const uint64_t x = TL[e];
+        if (e >= lead && x != KEY_INF) {
+          int rank = e - lead;
+#pragma unroll
+          for (int o = 1; o < 4; o++) rank += (int)tm_lower_bound16(Lw + (row * 4 + ((qd + o) & 3)) * 16, x) - lead;
+          if (rank < (int)A.m) out[rank] = x;
+        }
+      }
+    }
+    return;
+  }
   // ---- emit this block's partial lists ----
   for (uint32_t i = tid; i < na_tile * A.m; i += 256) {
     const uint32_t ar = i / A.m, j = i % A.m;
