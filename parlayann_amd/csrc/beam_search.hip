@@ -177,11 +177,6 @@ __device__ __forceinline__ uint32_t gather_distances(const BSParams& P, const QR
   return c;
 }
 
-__device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
-  const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, l);
-  const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), l);
-  return ((uint64_t)hi << 32) | lo;
-}
 
 // Generic kernel: any beam (frontier in LDS), filter in LDS or in HBM scratch.
 template <int DT, int METRIC, int LPC, bool NCH1, bool HASH_LDS>

@@ -151,10 +151,15 @@ struct MstArgs {
   const uint32_t* ids;             // position -> vertex id
   uint32_t* graph; uint32_t gstride; uint32_t max_deg; uint32_t* deg;
   uint32_t mst_deg;
+  uint32_t lds_cap;                // leaves up to this many members keep their Kruskal state in LDS
   int32_t* g_parent; uint8_t* g_rank; uint8_t* g_degree;    // HBM scratch indexed by position (large leaves)
 };
 
-// modified Kruskal of one leaf (hcnng_index.h:202-228) + process_edges (:117-131)
+// modified Kruskal of one leaf (hcnng_index.h:202-228) + process_edges (:117-131).
+// One wave per leaf.  Everything the sequential loop touches sits in LDS for leaves up to A.lds_cap members
+// (union-find arrays, the members' vertex ids and their degrees before this tree); the sorted edge keys are
+// fetched 64 at a time (one coalesced load per chunk, then wave-uniform readlane), so the walk never waits for
+// HBM; only the row appends are global stores.  Larger leaves keep the arrays in HBM scratch.
 __global__ void __launch_bounds__(PANN_WAVE) leaf_mst_kernel(MstArgs A) {
   const int lane = threadIdx.x;
   const uint32_t l = blockIdx.x;
@@ -162,12 +167,21 @@ __global__ void __launch_bounds__(PANN_WAVE) leaf_mst_kernel(MstArgs A) {
   const uint64_t lo = A.leaf_off[l];
   const uint32_t N = (uint32_t)(A.leaf_off[l + 1] - lo);
   if (N < 2) return;
-  const bool in_lds = N <= 4096;
+  const uint32_t cap = A.lds_cap;
+  const bool in_lds = N <= cap;
   int32_t* parent = in_lds ? reinterpret_cast<int32_t*>(smem) : A.g_parent + lo;
-  uint8_t* rnk = in_lds ? reinterpret_cast<uint8_t*>(smem + 4096 * 4) : A.g_rank + lo;
-  uint8_t* dgr = in_lds ? reinterpret_cast<uint8_t*>(smem + 4096 * 5) : A.g_degree + lo;
-  if (in_lds) { for (uint32_t i = lane; i < N; i += PANN_WAVE) { parent[i] = (int32_t)i; rnk[i] = 0; dgr[i] = 0; } }
-  else {
+  uint32_t* lids = reinterpret_cast<uint32_t*>(smem + (size_t)cap * 4);                  // [cap] vertex ids (LDS mode)
+  uint16_t* deg0 = reinterpret_cast<uint16_t*>(smem + (size_t)cap * 8);                  // [cap] row degree before this tree
+  uint8_t* rnk = in_lds ? reinterpret_cast<uint8_t*>(smem + (size_t)cap * 10) : A.g_rank + lo;
+  uint8_t* dgr = in_lds ? reinterpret_cast<uint8_t*>(smem + (size_t)cap * 11) : A.g_degree + lo;
+  if (in_lds) {
+    for (uint32_t i = lane; i < N; i += PANN_WAVE) {
+      parent[i] = (int32_t)i; rnk[i] = 0; dgr[i] = 0;
+      const uint32_t v = A.ids[lo + i];
+      lids[i] = v;
+      deg0[i] = (uint16_t)min(A.deg[v], 65535u);
+    }
+  } else {
     for (uint32_t i = lane; i < N; i += PANN_WAVE) {
       __hip_atomic_store(parent + i, (int32_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(rnk + i, (uint8_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -179,7 +193,7 @@ __global__ void __launch_bounds__(PANN_WAVE) leaf_mst_kernel(MstArgs A) {
   __syncthreads();
   const uint64_t* K = A.keys + lo * A.m;
   const uint64_t ne = (uint64_t)N * A.m;
-  // accessors: LDS for leaves up to 4096 members; HBM scratch (L1-bypassing loads/stores) beyond
+  // accessors: LDS for leaves up to lds_cap members; HBM scratch (L1-bypassing loads/stores) beyond
   auto ldp = [&](int i) -> int { return in_lds ? parent[i] : __hip_atomic_load(parent + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   auto stp = [&](int i, int v) { if (in_lds) parent[i] = v; else __hip_atomic_store(parent + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   auto ld8 = [&](uint8_t* a, int i) -> uint8_t { return in_lds ? a[i] : __hip_atomic_load(a + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
@@ -188,39 +202,65 @@ __global__ void __launch_bounds__(PANN_WAVE) leaf_mst_kernel(MstArgs A) {
   auto root_ro = [&](int x) { for (;;) { const int px = ldp(x); if (px == x) return x; x = px; } };
   uint64_t prev = KEY_INF;
   uint64_t e_unique = 0;      // index in the de-duplicated sequence (remove_duplicates_ordered :202-203)
-  for (uint64_t e = 0; e < ne; e++) {
-    const uint64_t key = K[e];            // uniform address: one broadcast load
-    if (key == KEY_INF) break;            // padding sorts last
-    if (key == prev) continue;
-    prev = key;
-    const int a = (int)((key >> 16) & 0xFFFF), b = (int)(key & 0xFFFF);
-    if (lane == 0) {
-      const int ra = find(a), rb = find(b);
-      const uint8_t da = ld8(dgr, a), db = ld8(dgr, b);
-      if (ra != rb && da < A.mst_deg && db < A.mst_deg) {
-        const uint32_t va = A.ids[lo + a], vb = A.ids[lo + b];
-        // MST_edges gets (a,b) then (b,a); process_edges appends while the row has room.  A vertex sits in
-        // exactly one leaf per tree, so its row position is (degree before this tree) + (edges of this leaf).
-        const uint32_t pa = A.deg[va] + da, pb = A.deg[vb] + db;
-        if (pa < A.max_deg) A.graph[(size_t)va * A.gstride + pa] = vb;
-        if (pb < A.max_deg) A.graph[(size_t)vb * A.gstride + pb] = va;
-        st8(dgr, a, da + 1); st8(dgr, b, db + 1);
-        const uint8_t ka = ld8(rnk, a), kb = ld8(rnk, b);     // the reference reads rank[x], not rank[root] (:53-54)
-        if (ka < kb) stp(ra, rb); else { stp(rb, ra); if (ka == kb) st8(rnk, ra, ld8(rnk, ra) + 1); }
+  bool done = false;
+  for (uint64_t e0 = 0; e0 < ne && !done; e0 += PANN_WAVE) {
+    const uint64_t kv = (e0 + lane < ne) ? K[e0 + lane] : KEY_INF;       // 64 sorted keys, one per lane
+    uint64_t before = __shfl_up(kv, 1);
+    if (lane == 0) before = prev;
+    const bool uniq = (kv != KEY_INF) && (kv != before);                 // padding sorts last
+    const int a = (int)((kv >> 16) & 0xFFFF), b = (int)(kv & 0xFFFF);
+    // Read-only pre-filter, all lanes at once.  Degrees only grow and sets only merge, so an edge that fails
+    // the degree or the same-set test NOW also fails it when its turn comes; the sequential walk below only
+    // visits the others (and re-tests them against the current state).
+    bool maybe = uniq;
+    if (maybe) {
+      if (ld8(dgr, a) >= A.mst_deg || ld8(dgr, b) >= A.mst_deg) maybe = false;
+      else if (root_ro(a) == root_ro(b)) maybe = false;
+    }
+    const uint64_t um = __ballot(uniq), mm = __ballot(maybe);
+    const uint64_t my_index = e_unique + lanes_below(um, lane);          // position in the de-duplicated sequence
+    const uint64_t cm = __ballot(uniq && (my_index % N == 0));           // :221-225 is due after these edges
+    uint64_t work = mm | cm;
+    while (work) {
+      const int j = __ffsll((unsigned long long)work) - 1;
+      work &= work - 1;
+      if ((mm >> j) & 1ull) {
+        const uint64_t key = readlane64(kv, j);                          // wave-uniform
+        const int ea = (int)((key >> 16) & 0xFFFF), eb = (int)(key & 0xFFFF);
+        if (lane == 0) {
+          const uint8_t da = ld8(dgr, ea), db = ld8(dgr, eb);
+          if (da < A.mst_deg && db < A.mst_deg) {
+            const int ra = find(ea), rb = find(eb);
+            if (ra != rb) {
+              // MST_edges gets (a,b) then (b,a); process_edges appends while the row has room.  A vertex sits in
+              // exactly one leaf per tree, so its row position is (degree before this tree) + (edges of this leaf).
+              const uint32_t va = in_lds ? lids[ea] : A.ids[lo + ea], vb = in_lds ? lids[eb] : A.ids[lo + eb];
+              const uint32_t pa = (in_lds ? (uint32_t)deg0[ea] : A.deg[va]) + da, pb = (in_lds ? (uint32_t)deg0[eb] : A.deg[vb]) + db;
+              if (pa < A.max_deg) A.graph[(size_t)va * A.gstride + pa] = vb;
+              if (pb < A.max_deg) A.graph[(size_t)vb * A.gstride + pb] = va;
+              st8(dgr, ea, da + 1); st8(dgr, eb, db + 1);
+              const uint8_t ka = ld8(rnk, ea), kb = ld8(rnk, eb);   // the reference reads rank[x], not rank[root] (:53-54)
+              if (ka < kb) stp(ra, rb); else { stp(rb, ra); if (ka == kb) st8(rnk, ra, ld8(rnk, ra) + 1); }
+            }
+          }
+        }
+      }
+      if ((cm >> j) & 1ull) {   // :221-225  every N processed edges: stop when everything is in one set
+        __threadfence_block();
+        __syncthreads();
+        const int r0 = root_ro(0);
+        bool all = true;
+        for (uint32_t i = lane; i < N; i += PANN_WAVE) all &= (root_ro((int)i) == r0);
+        const bool full = __ballot(!all) == 0ull;
+        __syncthreads();
+        if (full) { done = true; break; }
       }
     }
-    // :221-225  every N processed edges: stop when everything is in one set
-    if (e_unique % N == 0) {
-      __threadfence_block();
-      __syncthreads();
-      const int r0 = root_ro(0);
-      bool all = true;
-      for (uint32_t i = lane; i < N; i += PANN_WAVE) all &= (root_ro((int)i) == r0);
-      const bool full = __ballot(!all) == 0ull;
-      __syncthreads();
-      if (full) break;
-    }
-    e_unique++;
+    e_unique += __popcll(um);
+    prev = readlane64(kv, PANN_WAVE - 1);
+    if (prev == KEY_INF) done = true;                                    // the rest is padding
+    __threadfence_block();
+    __syncthreads();                                                     // lane 0's updates before the next pre-filter
   }
   __threadfence_block();
   __syncthreads();
@@ -376,7 +416,10 @@ int hcnng_build_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, uint32
     ma.keys = b_kb.as<uint64_t>(); ma.leaf_off = d_loff.as<uint64_t>(); ma.nleaves = nleaves; ma.m = m; ma.ids = ids;
     ma.graph = ix.graph; ma.gstride = ix.gstride; ma.max_deg = ix.max_deg; ma.deg = b_deg.as<uint32_t>(); ma.mst_deg = mst_deg;
     ma.g_parent = b_par.as<int32_t>(); ma.g_rank = b_rnk.as<uint8_t>(); ma.g_degree = b_dgr.as<uint8_t>();
-    hipLaunchKernelGGL(leaf_mst_kernel, dim3(nleaves), dim3(PANN_WAVE), 4096 * 6, st, ma);
+    uint64_t max_leaf = 2;
+    for (uint32_t l = 0; l < nleaves; l++) max_leaf = std::max<uint64_t>(max_leaf, leaf_off[l + 1] - leaf_off[l]);
+    ma.lds_cap = (uint32_t)std::min<uint64_t>((max_leaf + 63) / 64 * 64, 4096);     // 12 bytes of LDS per member
+    hipLaunchKernelGGL(leaf_mst_kernel, dim3(nleaves), dim3(PANN_WAVE), (size_t)ma.lds_cap * 12, st, ma);
     PANN_HIP(hipGetLastError());
     PANN_HIP(hipStreamSynchronize(st));
     const auto t3 = now();

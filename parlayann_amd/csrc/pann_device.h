@@ -372,6 +372,12 @@ __device__ __forceinline__ void load_query(const uint8_t* qrow, uint32_t valid, 
   }
 }
 
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
+  const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, l);
+  const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), l);
+  return ((uint64_t)hi << 32) | lo;
+}
+
 __device__ __forceinline__ uint32_t lanes_below(uint64_t m, int lane) {
   return __popcll(m & ((1ull << lane) - 1ull));
 }

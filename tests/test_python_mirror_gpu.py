@@ -181,6 +181,16 @@ def test_hcnng_build_identical_to_oracle(oracle, dtype, metric, d):
     np.testing.assert_array_equal(G, Go)
 
 
+@pytest.mark.parametrize("n,clusters,leaf,mst_deg", [(11000, 2, 5000, 3),      # leaves above 4096 members: Kruskal state in HBM scratch
+                                                     (3000, 3, 40, 2),          # many small leaves, some smaller than the 10-NN lists
+                                                     (2500, 2, 700, 5)])
+def test_hcnng_build_leaf_size_extremes(oracle, n, clusters, leaf, mst_deg):
+    X = datasets.sift_like(n, 64, seed=77, dtype=np.uint8)
+    G = wrapper.hcnng_build(X, "Euclidian", clusters, leaf, mst_deg, seed=3)
+    Go = oracle.hcnng_build(X, clusters, leaf, mst_deg, seed=3)
+    np.testing.assert_array_equal(G, Go)
+
+
 def test_parlayannpy_dropin_names():
     from parlayann_amd import _ParlayANNpy as m
     for cls in ("FloatEuclidianIndex", "FloatMipsIndex", "UInt8EuclidianIndex", "UInt8MipsIndex", "Int8EuclidianIndex",
