@@ -178,7 +178,10 @@ __global__ void __launch_bounds__(256) dense_topk_kernel(DenseArgs A) {
       stage_rows(Bt, DT_BSTRIDE, sg, b_rowptr, b_valid, nb_tile, TB);
       if (nseg > 1) stage_rows(At, DT_SEG, sg, a_rowptr, a_valid, na_tile, DT_A);
       __syncthreads();
-      const uint32_t nchunk = min((uint32_t)DT_SEG, A.pstride - sg * DT_SEG) / 16;
+      // chunks that hold only the rows' zero padding (d*esize .. pstride) add nothing: skip them
+      const uint32_t seg_bytes = min((uint32_t)DT_SEG, A.pstride - sg * DT_SEG);
+      const uint32_t seg_valid = A.dbytes > sg * DT_SEG ? min(seg_bytes, A.dbytes - sg * DT_SEG) : 0u;
+      const uint32_t nchunk = (seg_valid + 15) / 16;
       for (uint32_t c = 0; c < nchunk; c++) {
         // the lane's DT_RB B chunks are digested once (QReg); each of the 16 A chunks is ONE LDS broadcast
         // that feeds DT_RB accumulators (the LDS read rate, not the VALU, bounds this loop at DT_RB = 1)
