@@ -43,6 +43,21 @@ struct DevBuf {
   template <typename T> T* as() { return (T*)p; }
 };
 
+// growable pinned host buffer: host-pointer calls pack their inputs / outputs here so that each direction is ONE
+// DMA transfer (copies from or to pageable memory are staged and synchronised one by one by the runtime)
+struct PinnedBuf {
+  void* p = nullptr; size_t bytes = 0;
+  int ensure(size_t need) {
+    if (need <= bytes) return PANN_OK;
+    if (p) { PANN_HIP(hipHostFree(p)); p = nullptr; bytes = 0; }
+    size_t cap = need + need / 4 + 4096;
+    PANN_HIP(hipHostMalloc(&p, cap, hipHostMallocDefault));
+    bytes = cap;
+    return PANN_OK;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
+};
+
 }  // namespace pann
 
 using namespace pann;
@@ -54,6 +69,7 @@ struct pann_index {
   Workspace ws, ws2, ws3;   // kernel scratch (search / prune / re-prune)
   uint32_t vcap = 0;        // visited-list capacity used by the builder (grows on overflow)
   DevBuf stage[12];      // staging for host-pointer calls
+  PinnedBuf pin_in, pin_out;   // packed pinned staging of pann_batch_search
 };
 
 namespace {
@@ -210,6 +226,7 @@ void pann_index_destroy(pann_index* idx) {
   if (idx->ix.graph) (void)hipFree(idx->ix.graph);
   idx->ws.release(); idx->ws2.release(); idx->ws3.release();
   for (auto& s : idx->stage) s.release();
+  idx->pin_in.release(); idx->pin_out.release();
   if (idx->stream) (void)hipStreamDestroy(idx->stream);
   delete idx;
 }
@@ -313,69 +330,55 @@ static int batch_search_host(pann_index* idx, const void* queries, const uint32_
   DeviceGuard g(idx->device);
   hipStream_t st = idx->stream;
   const DeviceIndex& ix = idx->ix;
-  // stage inputs
-  const void* d_q = nullptr; const uint32_t* d_qid = nullptr;
-  if (queries) {
-    if (q_stride_bytes < ix.dbytes) { set_error("pann_batch_search: query stride smaller than a row"); return PANN_ERR_BAD_ARG; }
-    if (int rc = idx->stage[2].ensure(nq * q_stride_bytes + 16)) return rc;
-    PANN_HIP(hipMemcpyAsync(idx->stage[2].p, queries, (nq - 1) * q_stride_bytes + ix.dbytes, hipMemcpyHostToDevice, st));
-    d_q = idx->stage[2].p;
-  } else {
-    if (int rc = idx->stage[2].ensure(nq * 4)) return rc;
-    PANN_HIP(hipMemcpyAsync(idx->stage[2].p, query_ids, nq * 4, hipMemcpyHostToDevice, st));
-    d_qid = idx->stage[2].as<uint32_t>();
-  }
-  if (int rc = idx->stage[3].ensure((size_t)nst_total * 4)) return rc;
-  PANN_HIP(hipMemcpyAsync(idx->stage[3].p, starts, (size_t)nst_total * 4, hipMemcpyHostToDevice, st));
-  // device outputs
-  pann_search_out d = *out;
+  // ---- inputs: packed into pinned memory, one H2D transfer ----
+  if (queries && q_stride_bytes < ix.dbytes) { set_error("pann_batch_search: query stride smaller than a row"); return PANN_ERR_BAD_ARG; }
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t qbytes = queries ? (nq - 1) * q_stride_bytes + ix.dbytes : nq * 4;
+  const size_t off_st = al(qbytes + 16), in_bytes = off_st + al((size_t)nst_total * 4);
+  if (int rc = idx->pin_in.ensure(in_bytes)) return rc;
+  if (int rc = idx->stage[2].ensure(in_bytes)) return rc;
+  std::memcpy(idx->pin_in.p, queries ? queries : (const void*)query_ids, qbytes);
+  std::memcpy((uint8_t*)idx->pin_in.p + off_st, starts, (size_t)nst_total * 4);
+  PANN_HIP(hipMemcpyAsync(idx->stage[2].p, idx->pin_in.p, in_bytes, hipMemcpyHostToDevice, st));
+  const void* d_q = queries ? idx->stage[2].p : nullptr;
+  const uint32_t* d_qid = queries ? nullptr : idx->stage[2].as<uint32_t>();
+  const uint32_t* d_starts = (const uint32_t*)((uint8_t*)idx->stage[2].p + off_st);
+
+  // ---- outputs: one packed device region, one D2H transfer into pinned memory, then host copies ----
   const size_t ok = out->out_k, vc = out->visited_cap;
-  auto want = [&](DevBuf& b, const void* host, size_t bytes, void** dptr) -> int {
-    *dptr = nullptr;
-    if (!host || bytes == 0) return PANN_OK;
-    if (int rc = b.ensure(bytes)) return rc;
-    *dptr = b.p; return PANN_OK;
-  };
-  void *p_ids, *p_d, *p_fs, *p_vc, *p_dc, *p_ds, *p_vi, *p_vd;
-  if (int rc = want(idx->stage[4], out->ids, nq * ok * 4, &p_ids)) return rc;
-  if (int rc = want(idx->stage[5], out->dists, nq * ok * 4, &p_d)) return rc;
-  if (int rc = want(idx->stage[6], out->frontier_size, nq * 4, &p_fs)) return rc;
-  if (int rc = want(idx->stage[7], out->visited_count, nq * 4, &p_vc)) return rc;
-  if (int rc = want(idx->stage[8], out->dist_cmps, nq * 4, &p_dc)) return rc;
-  if (int rc = want(idx->stage[9], out->degree_sum, nq * 4, &p_ds)) return rc;
-  if (int rc = want(idx->stage[10], out->visited_ids, nq * vc * 4, &p_vi)) return rc;
-  if (int rc = want(idx->stage[11], out->visited_dists, nq * vc * 4, &p_vd)) return rc;
-  d.ids = (uint32_t*)p_ids; d.dists = (float*)p_d; d.frontier_size = (uint32_t*)p_fs;
-  d.visited_count = (uint32_t*)p_vc; d.dist_cmps = (uint32_t*)p_dc; d.degree_sum = (uint32_t*)p_ds;
-  d.visited_ids = (uint32_t*)p_vi; d.visited_dists = (float*)p_vd;
-  if (!p_vi && !p_vd) d.visited_cap = 0;
+  struct Piece { void* host; size_t bytes; size_t off; };
+  Piece pc[8] = {{out->ids, nq * ok * 4, 0}, {out->dists, nq * ok * 4, 0}, {out->frontier_size, nq * 4, 0},
+                 {out->visited_count, nq * 4, 0}, {out->dist_cmps, nq * 4, 0}, {out->degree_sum, nq * 4, 0},
+                 {out->visited_ids, nq * vc * 4, 0}, {out->visited_dists, nq * vc * 4, 0}};
+  size_t out_bytes = 0;
+  for (auto& x : pc) { if (!x.host) x.bytes = 0; x.off = out_bytes; out_bytes += al(x.bytes); }
+  if (int rc = idx->stage[4].ensure(out_bytes + 256)) return rc;
+  if (int rc = idx->pin_out.ensure(out_bytes + 256)) return rc;
+  auto dptr = [&](int i) -> void* { return pc[i].bytes ? (void*)((uint8_t*)idx->stage[4].p + pc[i].off) : nullptr; };
+  pann_search_out d = *out;
+  d.ids = (uint32_t*)dptr(0); d.dists = (float*)dptr(1); d.frontier_size = (uint32_t*)dptr(2);
+  d.visited_count = (uint32_t*)dptr(3); d.dist_cmps = (uint32_t*)dptr(4); d.degree_sum = (uint32_t*)dptr(5);
+  d.visited_ids = (uint32_t*)dptr(6); d.visited_dists = (float*)dptr(7);
+  if (!d.visited_ids && !d.visited_dists) d.visited_cap = 0;
 
   int rc;
   {
     SearchArgs a;
     a.queries = (const uint8_t*)d_q; a.qstride = q_stride_bytes; a.query_ids = d_qid;
-    a.nq = nq; a.starts = idx->stage[3].as<uint32_t>(); a.nstarts = nstarts; a.starts_per_query = per_query;
+    a.nq = nq; a.starts = d_starts; a.nstarts = nstarts; a.starts_per_query = per_query;
     a.k = qp->k; a.beam = qp->beam; a.limit = qp->limit; a.degree_limit = qp->degree_limit; a.cut = qp->cut;
     a.out = d;
     if ((rc = idx->ws.ensure(search_workspace_bytes(idx->ix, a)))) return rc;
     rc = launch_beam_search(idx->ix, a, idx->ws.buf, idx->ws.bytes, st);
   }
   if (rc) return rc;
-  auto back = [&](void* host, void* dev, size_t bytes) -> hipError_t {
-    if (!host || !dev || !bytes) return hipSuccess;
-    return hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st);
-  };
-  PANN_HIP(back(out->ids, p_ids, nq * ok * 4));
-  PANN_HIP(back(out->dists, p_d, nq * ok * 4));
-  PANN_HIP(back(out->frontier_size, p_fs, nq * 4));
-  PANN_HIP(back(out->visited_count, p_vc, nq * 4));
-  PANN_HIP(back(out->dist_cmps, p_dc, nq * 4));
-  PANN_HIP(back(out->degree_sum, p_ds, nq * 4));
-  PANN_HIP(back(out->visited_ids, p_vi, nq * vc * 4));
-  PANN_HIP(back(out->visited_dists, p_vd, nq * vc * 4));
-  uint32_t status = 0;
-  PANN_HIP(hipMemcpyAsync(&status, (uint8_t*)idx->ws.buf + 64, 4, hipMemcpyDeviceToHost, st));
+  // the status word travels with the results
+  PANN_HIP(hipMemcpyAsync((uint8_t*)idx->stage[4].p + out_bytes, (uint8_t*)idx->ws.buf + 64, 4, hipMemcpyDeviceToDevice, st));
+  PANN_HIP(hipMemcpyAsync(idx->pin_out.p, idx->stage[4].p, out_bytes + 4, hipMemcpyDeviceToHost, st));
   PANN_HIP(hipStreamSynchronize(st));
+  for (auto& x : pc) if (x.bytes) std::memcpy(x.host, (uint8_t*)idx->pin_out.p + x.off, x.bytes);
+  uint32_t status = 0;
+  std::memcpy(&status, (uint8_t*)idx->pin_out.p + out_bytes, 4);
   if (status & 1u) { set_error("pann_batch_search: visited list longer than visited_cap"); return PANN_ERR_OVERFLOW; }
   if (status & 2u) { set_error("pann_batch_search: internal dropped-list overflow"); return PANN_ERR_OVERFLOW; }
   return PANN_OK;
