@@ -71,6 +71,7 @@ struct BSParams {
   uint32_t bits;           // log2 of filter size (:52)
   uint32_t bcap, ccap;     // LDS capacities (multiples of 64)
   uint32_t* hash_global;   // [slots][1<<bits] when the filter does not fit LDS
+  uint32_t hsplit;         // beam 65..128 in HBM mode: 0 whole table in HBM, 1 half, 2 three quarters of it in LDS
   uint64_t* dropped; uint32_t dcap;  // [nq][dcap] visited entries that left a non-full frontier
   uint32_t* work_counter;  // persistent variant: next query to take
   uint32_t* status;        // [0] |= 1 on visited-list overflow, |= 2 on dropped-list overflow
@@ -113,11 +114,20 @@ __device__ __forceinline__ uint32_t lower_bound_lds(const uint64_t* A, uint32_t 
 // back: into the table itself when it lives in LDS; into a 1 KB LDS scratch T (index = slot mod 1024,
 // false sharing only costs a loop trip) when the table lives in HBM, which then sees ONE dependent
 // load (the entry values) and one fire-and-forget store per call instead of four round trips.
+// Split mode (HBM branch, hb = 1 or 2): the slots whose low hb bits are all ones live in HBM (index s >> hb), the
+// other half / three quarters in LDS right after T -- fewer single-word L2 requests per row for a smaller LDS
+// footprint than the whole table.
+__device__ __forceinline__ uint32_t split_lds_index(uint32_t s, uint32_t hb) {
+  return hb == 1 ? (s >> 1) : (s >> 2) * 3 + (s & 3);
+}
 template <bool HASH_LDS>
 __device__ __forceinline__ bool filter_update(uint32_t* H, uint32_t hmask, bool active, uint32_t a, int lane,
-                                              uint8_t* T = nullptr) {
+                                              uint8_t* T = nullptr, uint32_t hb = 0) {
   const uint32_t s = (uint32_t)hash64_2((uint64_t)a) & hmask;
   uint32_t old, w;
+  const uint32_t hm = (1u << hb) - 1u;
+  const bool in_hbm = (s & hm) == hm;                                   // always true when hb == 0
+  uint32_t* Hp = reinterpret_cast<uint32_t*>(T + 1024);                 // LDS part of a split table
   if constexpr (HASH_LDS) {
     old = active ? H[s] : 0u;
     __syncthreads();
@@ -126,7 +136,8 @@ __device__ __forceinline__ bool filter_update(uint32_t* H, uint32_t hmask, bool 
     w = active ? H[s] : (uint32_t)lane;
   } else {
     __builtin_amdgcn_s_waitcnt(0);                       // the previous call's table stores have been acknowledged
-    old = active ? __hip_atomic_load(H + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    old = 0u;
+    if (active) old = in_hbm ? __hip_atomic_load(H + (s >> hb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : Hp[split_lds_index(s, hb)];
     const uint32_t t = s & 1023u;
     if (active) T[t] = (uint8_t)lane;
     __syncthreads();
@@ -153,8 +164,11 @@ __device__ __forceinline__ bool filter_update(uint32_t* H, uint32_t hmask, bool 
     if (active && last) H[s] = a;
     __syncthreads();
   } else {
-    if (active && last) __hip_atomic_store(H + s, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();                                     // T may be rewritten by the next call
+    if (active && last) {
+      if (in_hbm) __hip_atomic_store(H + (s >> hb), a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else Hp[split_lds_index(s, hb)] = a;
+    }
+    __syncthreads();                                     // T (and the LDS part) may be touched by the next call
   }
   return seen;
 }
@@ -661,7 +675,9 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
   }
   while (qi < P.nq) {
   uint32_t* H = HASH_LDS ? Hl : P.hash_global + ((size_t)blockIdx.x << P.bits);
-  for (uint32_t i = lane; i < hsize; i += PANN_WAVE) hstore<HASH_LDS>(H, i, SENTINEL);
+  const uint32_t hb = HASH_LDS ? 0u : P.hsplit;
+  for (uint32_t i = lane; i < (hsize >> hb); i += PANN_WAVE) hstore<HASH_LDS>(H, i, SENTINEL);
+  if (hb) for (uint32_t i = lane; i < hsize - (hsize >> hb); i += PANN_WAVE) reinterpret_cast<uint32_t*>(T + 1024)[i] = SENTINEL;
   const int64_t self = P.query_ids ? (int64_t)P.query_ids[qi] : -1;
   const uint8_t* qrow = P.query_ids ? P.points + (uint64_t)self * P.pstride : P.queries + (uint64_t)qi * P.qstride;
   QReg<DT> qreg{};
@@ -683,7 +699,7 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
   {   // start points (:66-70); nstarts <= 64 in this kernel
     const bool act = lane < (int)P.nstarts;
     const uint32_t a = act ? P.starts[(size_t)qi * P.starts_stride + lane] : 0u;
-    (void)filter_update<HASH_LDS>(H, hmask, act, a, lane, T);
+    (void)filter_update<HASH_LDS>(H, hmask, act, a, lane, T, hb);
     if (act) Pl[lane] = a;
     __syncthreads();
     c = gather_distances<DT, METRIC, LPC, NCH1, 4>(P, qreg, qlds, Pl, P.nstarts, 0xFFFFFFFFu, C, c, lane);
@@ -725,7 +741,7 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
         PANN_STAMP(1);
         if (am == 0ull) break;
         degsum += __popcll(am);
-        const bool seen = filter_update<HASH_LDS>(H, hmask, act, a, lane, T);
+        const bool seen = filter_update<HASH_LDS>(H, hmask, act, a, lane, T, hb);
         const bool keep = act && !seen && ((int64_t)a != self);
         const uint64_t km = __ballot(keep);
         const uint32_t m = __popcll(km);
@@ -886,6 +902,7 @@ static uint32_t filter_bits(int64_t beam) {  // :52
 struct Plan {
   uint32_t bits, bcap, ccap, deg_eff, dcap, lds_bytes; bool hash_lds; uint32_t slots; bool b64; bool b128;
   bool b128_hbm;   // beam 65..128 with the filter in HBM (persistent blocks)
+  uint32_t hsplit; // ... of which the part with an LDS share (filter_update split mode)
 };
 
 static Plan make_plan(const DeviceIndex& ix, const SearchArgs& a) {
@@ -920,7 +937,14 @@ static Plan make_plan(const DeviceIndex& ix, const SearchArgs& a) {
     // L2 request rate the new limit (in-kernel stamps: every phase 2-3x longer at 3x the occupancy).
     static const bool force_lds = getenv("PANN_B128_LDS") != nullptr;       // diagnostic A/B switch
     p.b128_hbm = (hbytes > 8192) && a.nq > 2048 && !force_lds;
-    if (p.b128_hbm) { p.hash_lds = false; hbytes = 1024; p.slots = 256 * 32; }   // one table per block, >= the resident waves
+    p.hsplit = 0;
+    if (p.b128_hbm) {   // one table per block, >= the resident waves
+      static const char* sp = getenv("PANN_B128_SPLIT");
+      p.hsplit = sp ? (uint32_t)atoi(sp) : 1u;     // measured: half in LDS 2.99 M q/s, none 2.46, three quarters 2.67, whole table in LDS 2.28
+      if (p.hsplit > 2) p.hsplit = 0;
+      p.hash_lds = false; p.slots = 256 * 32;
+      hbytes = 1024 + (p.hsplit ? (((size_t)1 << p.bits) - ((size_t)1 << (p.bits - p.hsplit))) * 4 : 0);
+    }
     p.lds_bytes = (uint32_t)(128 * 8 + (size_t)p.ccap * 8 + 128 + (nch1 ? 0 : (size_t)ix.nch * ix.lpc * 16) + hbytes);
   }
   return p;
@@ -1009,6 +1033,7 @@ int launch_beam_search(const DeviceIndex& ix, const SearchArgs& a, void* ws, siz
   uint8_t* w = (uint8_t*)ws;
   P.work_counter = (uint32_t*)w; P.status = (uint32_t*)(w + 64);
   P.dropped = (uint64_t*)(w + 256); P.dcap = p.dcap;
+  P.hsplit = p.b128_hbm ? p.hsplit : 0u;
   P.hash_global = p.hash_lds ? nullptr : (uint32_t*)(w + 256 + (size_t)a.nq * p.dcap * 8);
   P.out = a.out;
   P.stamps = nullptr;

@@ -175,3 +175,23 @@ def test_per_query_starts_like_beamSearchRandom(oracle):
             np.testing.assert_array_equal(o["ids"][0], g["ids"][i])
             assert o["dist_cmps"][0] == g["dist_cmps"][i] and o["visited_count"][0] == g["visited_count"][i]
     ix.close()
+
+
+@pytest.mark.parametrize("dtype,d,beam", [(np.uint8, 128, 128), (np.float32, 96, 100), (np.float16, 128, 90)])
+def test_search_large_batches_beam_65_to_128(oracle, dtype, d, beam):
+    """more than 2048 queries at beam 65..128 take the persistent kernel whose filter table is split between LDS
+    and HBM (beam_search.hip make_plan): results and counters must not depend on where the table lives"""
+    n, nq = 6000, 2600
+    X, _, G = _setup(oracle, n, d, dtype, "l2", R=32, L=64, nq=10)
+    Q = _data(nq, d, dtype, 777)
+    ix = DeviceIndex(X, G)
+    for k, cut in ((10, 1.35), (0, 0.0)):
+        o = oracle.batch_search(X, G, queries=Q, k=k, beam=beam, cut=cut, out_k=beam)
+        g = ix.batch_search(Q, k=k, beam=beam, cut=cut, out_k=beam)
+        _compare(o, g)
+    # base-point queries with visited lists (the builder's mode)
+    qid = np.arange(nq, dtype=np.uint32) % n
+    o = oracle.batch_search(X, G, query_ids=qid, k=0, beam=beam, cut=0.0, out_k=beam, visited_cap=4 * beam)
+    g = ix.batch_search(query_ids=qid, k=0, beam=beam, cut=0.0, out_k=beam, visited_cap=4 * beam)
+    _compare(o, g, visited=True)
+    ix.close()
