@@ -91,6 +91,20 @@ def test_full_build_identical_graph(oracle, dtype, metric, d, n, R, L, passes):
     ix.close()
 
 
+def test_build_with_batches_above_2048_inserts(oracle):
+    """n = 110 000 -> insert batches of 2 200 (max_batch = 0.02 n, vamana/index.h:206-207): with L in 65..128 the
+    builder's searches run on the persistent beam-128 kernel with the split LDS/HBM filter; the graph must still be
+    identical to the oracle's"""
+    n, d, R, L = 110_000, 32, 16, 70
+    X = datasets.sift_like(n, d, seed=1234, dtype=np.uint8)
+    Go, so = oracle.vamana_build(X, R, L, 1.2, num_passes=1, seed=3)
+    ix = DeviceIndex(X, max_degree=R)
+    st = ix.vamana_build(R, L, 1.2, num_passes=1, seed=3)
+    np.testing.assert_array_equal(_norm(Go), _norm(ix.get_graph()))
+    assert int(so[0]) == st.search_dist_cmps and int(so[1]) == st.prune_dist_cmps
+    ix.close()
+
+
 def test_real_valued_build_matches_oracle_quality(oracle):
     """DEEP-shaped (real-valued, unit-norm) f32: device and CPU sum floats in different orders
     (DESIGN.md "float order"), so graphs are not bit-identical; north_star asks for recall within
