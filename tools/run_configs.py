@@ -145,6 +145,47 @@ def c4shard(n):
     print(json.dumps(out), flush=True)
 
 
+def _fill_chunk(args):
+    path, n_total, d, lo, hi, seed = args
+    mm = np.memmap(path, dtype=np.float16, mode="r+", shape=(n_total, d))
+    # every slice has its own 256 cluster centres (a larger corpus has more modes, not denser ones); queries use slice 0's
+    x = datasets._mixture(hi - lo, d, seed, 256, 16, center_scale=22.0, basis_scale=9.0, noise_scale=12.0, centers_seed=seed)
+    mm[lo:hi] = np.clip(np.rint(x + 100.0), 0, 255).astype(np.float16)
+    mm.flush()
+    return hi - lo
+
+
+def c4full(n):
+    """all of C4 (synthetic 100M x 128 fp16) on ONE MI355X: 25.6 GB of points + 25.6 GB of graph in its 288 GB of HBM;
+    the base is generated by 8 worker processes into a shared memory map (seeds 1234..1241, one per 12.5M slice)"""
+    import multiprocessing as mp
+    d, parts = 128, 8
+    path = "/dev/shm/pann_c4_base.f16"
+    t0 = time.time()
+    mm = np.memmap(path, dtype=np.float16, mode="w+", shape=(n, d)); del mm
+    step = (n + parts - 1) // parts
+    with mp.get_context("spawn").Pool(parts) as pool:
+        pool.map(_fill_chunk, [(path, n, d, i * step, min(n, (i + 1) * step), 1234 + i) for i in range(parts)])
+    X = np.memmap(path, dtype=np.float16, mode="r", shape=(n, d))
+    qs = [datasets._mixture(10_000 // parts, d, 4321 + i, 256, 16, center_scale=22.0, basis_scale=9.0, noise_scale=12.0,
+                            centers_seed=1234 + i) for i in range(parts)]       # queries from every slice's mixture
+    Q = np.clip(np.rint(np.concatenate(qs) + 100.0), 0, 255).astype(np.float16)
+    tg = time.time() - t0
+    try:
+        t0 = time.time(); ix = DeviceIndex(X, max_degree=64); tu = time.time() - t0
+        t0 = time.time(); st = ix.vamana_build(64, 128, 1.15, num_passes=2, seed=1); tb = time.time() - t0
+        t0 = time.time(); gt, gd = ix.bruteforce_knn(Q, 100); tgt = time.time() - t0
+        out = {"config": f"C4 on one GPU: {n}x128 fp16 Vamana R=64 L=128 a=1.15 x2, 10K queries", "datagen_s": tg, "upload_s": tu,
+               "build_s": tb, "groundtruth_s": tgt,
+               "build_phases_s": {"search": st.t_search_s, "prune": st.t_prune_s, "bidirect": st.t_bidirect_s, "reprune": st.t_reprune_s}}
+        for beam in (32, 64, 128):
+            ids, vis, cm, qps = device_qps(ix, Q, 10, beam)
+            out[f"beam{beam}"] = {"recall": recall_at_k(ids, gt, gd, 10), "visited": vis, "cmps": cm, "qps_device_resident": qps}
+        print(json.dumps(out), flush=True)
+    finally:
+        os.remove(path)
+
+
 if __name__ == "__main__":
     for a in sys.argv[1:] or ["c1"]:
         name, _, arg = a.partition(":")
@@ -158,3 +199,5 @@ if __name__ == "__main__":
             c5(int(arg or 1_000_000))
         elif name == "c4shard":
             c4shard(int(arg or 12_500_000))
+        elif name == "c4full":
+            c4full(int(arg or 100_000_000))
