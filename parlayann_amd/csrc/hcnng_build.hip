@@ -311,6 +311,11 @@ int hcnng_build_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, uint32
   hipLaunchKernelGGL(degree_init_kernel, dim3((uint32_t)n), dim3(64), 0, st, ix.graph, ix.gstride, b_deg.as<uint32_t>(), n);
   PANN_HIP(hipGetLastError());
 
+  // per-level buffers, sized once for the worst level: clusters that still split are longer than cluster_size
+  const size_t ncl_cap = (size_t)(n / cluster_size) + 2, nt_cap = (size_t)(n / 64) + ncl_cap + 2;
+  HBuf d_sc, d_tcl, d_toff, d_same, d_scat, d_n0;
+  if (d_sc.alloc(ncl_cap * sizeof(SplitCluster)) || d_tcl.alloc(nt_cap * 4) || d_toff.alloc(nt_cap * 4) || d_same.alloc(ncl_cap * 4) ||
+      d_scat.alloc(ncl_cap * sizeof(ScatterCluster)) || d_n0.alloc(ncl_cap * 4)) { set_error("pann_hcnng_build: hipMalloc failed"); return PANN_ERR_HIP; }
   struct Cl { uint32_t lo, len; uint64_t rnd; };
   double t_tree = 0, t_leaf = 0, t_mst = 0;
   for (uint32_t t = 0; t < num_clusters; t++) {
@@ -335,9 +340,7 @@ int hcnng_build_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, uint32
       for (size_t ci = 0; ci < sc.size(); ci++)
         for (uint32_t o = 0; o < sc[ci].len; o += 64) { tile_cl.push_back((uint32_t)ci); tile_off.push_back(o); }
       const size_t nt = tile_cl.size(), ncl = sc.size();
-      HBuf d_sc, d_tcl, d_toff, d_same, d_scat;
-      if (d_sc.alloc(ncl * sizeof(SplitCluster)) || d_tcl.alloc(nt * 4) || d_toff.alloc(nt * 4) || d_same.alloc(ncl * 4) ||
-          d_scat.alloc(ncl * sizeof(ScatterCluster))) { set_error("pann_hcnng_build: hipMalloc failed"); return PANN_ERR_HIP; }
+      if (ncl > ncl_cap || nt > nt_cap) { set_error("pann_hcnng_build: internal level buffer overflow"); return PANN_ERR_OVERFLOW; }
       PANN_HIP(hipMemcpyAsync(d_sc.p, sc.data(), ncl * sizeof(SplitCluster), hipMemcpyHostToDevice, st));
       PANN_HIP(hipMemcpyAsync(d_tcl.p, tile_cl.data(), nt * 4, hipMemcpyHostToDevice, st));
       PANN_HIP(hipMemcpyAsync(d_toff.p, tile_off.data(), nt * 4, hipMemcpyHostToDevice, st));
@@ -350,8 +353,6 @@ int hcnng_build_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, uint32
       PANN_HIP(rocprim::exclusive_scan(b_tmp.p, tb, b_first.as<uint32_t>(), b_scan.as<uint32_t>(), 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st));
       // per-cluster first-side counts and identical-pivot flags back to the host (a few KB)
       std::vector<uint32_t> h_same(ncl), h_n0(ncl);
-      HBuf d_n0;
-      if (d_n0.alloc(ncl * 4)) { set_error("pann_hcnng_build: hipMalloc failed"); return PANN_ERR_HIP; }
       hipLaunchKernelGGL(cluster_counts_kernel, dim3((uint32_t)((ncl + 255) / 256)), dim3(256), 0, st, b_scan.as<uint32_t>(),
                          d_sc.as<SplitCluster>(), (uint32_t)ncl, d_n0.as<uint32_t>());
       PANN_HIP(hipMemcpyAsync(h_same.data(), d_same.p, ncl * 4, hipMemcpyDeviceToHost, st));
@@ -374,7 +375,7 @@ int hcnng_build_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, uint32
       hipLaunchKernelGGL(tree_scatter_kernel, dim3((uint32_t)nt), dim3(64), 0, st, ids, newids, b_first.as<uint32_t>(),
                          b_scan.as<uint32_t>(), d_scat.as<ScatterCluster>(), d_tcl.as<uint32_t>(), d_toff.as<uint32_t>());
       PANN_HIP(hipGetLastError());
-      PANN_HIP(hipStreamSynchronize(st));   // the per-level buffers go out of scope
+      PANN_HIP(hipStreamSynchronize(st));   // the host vectors of this level go out of scope
       std::swap(ids, newids);
       level.swap(next);
     }
