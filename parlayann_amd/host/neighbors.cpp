@@ -4,12 +4,15 @@
 // -graph_path -graph_outfile -data_type {uint8,int8,float} -dist_func {Euclidian,mips} -k -Q -R -L
 // -alpha -num_passes -cluster_size -mst_deg -num_clusters -alg {vamana,hcnng} -device -seed -device_build {1,0}
 // -self 1 -range 1 -radius -radius_2 [-use_existing 1]  (vamana/neighbors.h:86-104)
+// -quantize_bits 8 with -data_type float  (neighborsTime.C:157-164,190-197)
 #include <cstring>
 #include <map>
 #include <string>
+#include <type_traits>
 
 #include "check_nn_recall.h"
 #include "hcnng_index.h"
+#include "quantize.h"
 #include "vamana_index.h"
 
 using namespace parlayANN;
@@ -24,11 +27,43 @@ struct Args {
 };
 
 template <class Point>
+int run_on(const Args& a, PointRange<Point>& Points, PointRange<Point>* QueriesIn);
+
+template <class Point>
 int run(const Args& a) {
   using PR = PointRange<Point>;
   const char* base = a.str("-base_path");
   if (!base) { std::cout << "usage: neighbors -base_path <b> [-graph_path <g>] [-query_path <q> -gt_path <gt>] ..." << std::endl; return 1; }
   PR Points(base);
+  if (a.str("-query_path")) { PR Queries(a.str("-query_path")); return run_on<Point>(a, Points, &Queries); }
+  return run_on<Point>(a, Points, nullptr);
+}
+
+// -data_type float -quantize_bits 8 (neighborsTime.C:157-164, 190-197): base and queries are translated with the
+// BASE range's parameters, everything downstream (build, search) sees only the one-byte points
+template <bool MIPS>
+int run_quantized(const Args& a) {
+  using FP = typename std::conditional<MIPS, Mips_Point<float>, Euclidian_Point<float>>::type;
+  const char* base = a.str("-base_path");
+  if (!base) { std::cout << "usage: neighbors -base_path <b> ..." << std::endl; return 1; }
+  PointRange<FP> Points(base);
+  std::cout << "quantizing data to 1 byte" << std::endl;
+  if constexpr (MIPS) {
+    const float mv = generate_max_val_mips_i8(Points, false);              // Quantized_Mips_Point<8>: trim = false (:193)
+    auto QP = quantize_mips_i8(Points, mv);
+    if (a.str("-query_path")) { PointRange<FP> Qf(a.str("-query_path")); auto QQ = quantize_mips_i8(Qf, mv); return run_on<Mips_Point<int8_t>>(a, QP, &QQ); }
+    return run_on<Mips_Point<int8_t>>(a, QP, nullptr);
+  } else {
+    const euclid_u8_parameters pm = generate_parameters_u8(Points);
+    auto QP = quantize_u8(Points, pm);
+    if (a.str("-query_path")) { PointRange<FP> Qf(a.str("-query_path")); auto QQ = quantize_u8(Qf, pm); return run_on<Euclidian_Point<uint8_t>>(a, QP, &QQ); }
+    return run_on<Euclidian_Point<uint8_t>>(a, QP, nullptr);
+  }
+}
+
+template <class Point>
+int run_on(const Args& a, PointRange<Point>& Points, PointRange<Point>* QueriesIn) {
+  using PR = PointRange<Point>;
   const std::string alg = a.str("-alg") ? a.str("-alg") : "vamana";
   const long k = a.num("-k", 10), Q = a.num("-Q", 64);
   BuildParams BP;
@@ -56,8 +91,8 @@ int run(const Args& a) {
   size_t tot = 0, mx = 0;
   for (size_t i = 0; i < G.size(); i++) { tot += G[(indexType)i].size(); mx = std::max(mx, G[(indexType)i].size()); }
   std::cout << "Graph has average degree " << (double)tot / G.size() << " and maximum degree " << mx << std::endl;
-  if (a.str("-query_path")) {
-    PR Queries(a.str("-query_path"));
+  if (QueriesIn) {
+    PR& Queries = *QueriesIn;
     groundTruth<indexType> GT(a.str("-gt_path"));
     DeviceIndex<PR, indexType> DI(Points, &G, 0, (int)a.num("-device", 0));
     QueryParams QP(k, Q, 1.35, (long)G.size(), (long)G.max_degree());   // check_nn_recall.h:219,224
@@ -97,6 +132,9 @@ int main(int argc, char** argv) {
   const bool mips = df == "mips";
   if (dt == "uint8") return mips ? run<Mips_Point<uint8_t>>(a) : run<Euclidian_Point<uint8_t>>(a);
   if (dt == "int8") return mips ? run<Mips_Point<int8_t>>(a) : run<Euclidian_Point<int8_t>>(a);
+  const long qbits = a.num("-quantize_bits", 0);
+  if (dt == "float" && qbits == 8) return mips ? run_quantized<true>(a) : run_quantized<false>(a);
+  if (qbits != 0) { std::cout << "Error: -quantize_bits supports 8 with -data_type float (16 is not mirrored)" << std::endl; abort(); }
   if (dt == "float") return mips ? run<Mips_Point<float>>(a) : run<Euclidian_Point<float>>(a);
   std::cout << "Error: data type not specified correctly, specify int8, uint8, or float" << std::endl;   // neighborsTime.C:143-150
   abort();

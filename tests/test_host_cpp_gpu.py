@@ -102,6 +102,37 @@ def test_cli_self_range_search(exe, files, oracle):
     assert int(re.findall(r"comparisons during range = ([0-9]+)", out)[0]) == int(o["dist_cmps"].sum())
 
 
+@pytest.mark.parametrize("dist", ["Euclidian", "mips"])
+def test_cli_quantize_bits_8(exe, tmp_path, oracle, dist):
+    """-data_type float -quantize_bits 8 (neighborsTime.C:157-164,190-197): the C++ mirror's quantisers
+    (host/quantize.h) must give the oracle's one-byte points, hence the oracle's graph and recall."""
+    n, nq = 6000, 200
+    if dist == "Euclidian":
+        X, Q = datasets.deep_like(n, 96, seed=1234) * 3.0 - 0.2, datasets.deep_like(nq, 96, seed=4321) * 3.0 - 0.2
+        slope, off = oracle.euclid_u8_params(X)
+        Xq, Qq, metric = oracle.euclid_u8_translate(X, slope, off), oracle.euclid_u8_translate(Q, slope, off), "l2"
+    else:
+        X, Q = datasets.t2i_like(n, 100, seed=1234), datasets.t2i_like(nq, 100, seed=4321)
+        mv = oracle.mips_i8_maxval(X, trim=False)
+        Xq, Qq, metric = oracle.mips_i8_translate(X, mv), oracle.mips_i8_translate(Q, mv), "mips"
+    gt, gd = oracle.bruteforce_knn(X, Q, 100, metric)                         # ground truth in float space, like the CLI's -gt_path
+    io.write_bin(tmp_path / "b.fbin", X.astype(np.float32)); io.write_bin(tmp_path / "q.fbin", Q.astype(np.float32))
+    io.write_ibin(tmp_path / "gt.ibin", gt, gd)
+    alpha = 1.2 if dist == "Euclidian" else 1.0
+    out = _run(exe, "-base_path", tmp_path / "b.fbin", "-query_path", tmp_path / "q.fbin", "-gt_path", tmp_path / "gt.ibin",
+               "-graph_outfile", tmp_path / "g.graph", "-data_type", "float", "-dist_func", dist, "-quantize_bits", 8,
+               "-R", 32, "-L", 64, "-alpha", alpha, "-k", 10, "-Q", 64, "-seed", 5)
+    assert "quantizing data to 1 byte" in out
+    G = io.read_graph(tmp_path / "g.graph")
+    Go, _ = oracle.vamana_build(Xq, 32, 64, alpha, num_passes=1, seed=5, metric=metric)
+    cols = np.arange(32)[None, :]
+    np.testing.assert_array_equal(G[:, 0], Go[:, 0])
+    np.testing.assert_array_equal(np.where(cols < G[:, :1], G[:, 1:], 0), np.where(cols < Go[:, :1], Go[:, 1:], 0))
+    o = oracle.batch_search(Xq, Go, queries=Qq, k=10, beam=64, metric=metric)
+    rec = float(re.findall(r"recall=([0-9.]+)", out)[0])
+    assert abs(rec - oracle.recall(o["ids"], gt, gd, 10)) < 1e-6 and rec > 0.8
+
+
 def test_pivot_split_matches_oracle_distances(oracle):
     X = datasets.sift_like(3000, 96, seed=1, dtype=np.float32)
     ix = DeviceIndex(X, max_degree=8)
