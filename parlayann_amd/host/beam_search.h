@@ -3,6 +3,7 @@
 // qsearchAll (:537-565).
 // Each call is ONE pann_batch_search over the whole batch (the parallel_for seam :374/:556).
 #pragma once
+#include <algorithm>
 #include <utility>
 #include <vector>
 
@@ -99,6 +100,50 @@ std::vector<std::vector<indexType>> qsearchAll(PointRange& Query_Points, DeviceI
                                                const QueryParams& QP) {
   QueryParams q = QP;
   return searchAll<PointRange, indexType>(Query_Points, DI, QueryStats, starting_point, q);
+}
+
+// qsearchAll<PR, QPR, QQPR> (:537-565) = beam_search_rerank (:390-454) for every query, as TWO launches: the beam
+// search runs on the quantised mirror (Q_Query_Points against QDI), then the first min(k * rerank_factor, |beam|)
+// frontier ids are re-scored with the full-precision query against the full-precision mirror, sorted by (dist,id),
+// and the first k kept (:426-444).  When both ranges have the same num_bytes() nothing is re-sorted: the first k
+// frontier ids with their exact distances (:445-452).  The second-level filter (QQ ranges, use_filtering) is
+// out of scope; the QQ arguments of the reference equal the Q ones in every configuration mirrored here.
+template <class PointRange, class QPointRange, typename indexType>
+std::vector<std::vector<indexType>> qsearchAll(PointRange& Query_Points, QPointRange& Q_Query_Points,
+                                               DeviceIndex<PointRange, indexType>& DI, DeviceIndex<QPointRange, indexType>& QDI,
+                                               stats<indexType>& QueryStats, const indexType starting_point,
+                                               const QueryParams& QP, std::vector<float>* dists_out = nullptr) {
+  if (QP.k > QP.beamSize) {
+    std::cout << "Error: beam search parameter Q = " << QP.beamSize << " same size or smaller than k = " << QP.k << std::endl;
+    abort();
+  }
+  const size_t nq = Query_Points.size();
+  const uint32_t k = (uint32_t)QP.k, beam = (uint32_t)QP.beamSize;
+  const bool use_rerank = Query_Points.params.num_bytes() != Q_Query_Points.params.num_bytes();     // :409
+  std::vector<uint32_t> ids(nq * beam), fs(nq), vc(nq), dc(nq);
+  pann_search_out out{};
+  out.ids = ids.data(); out.out_k = beam; out.frontier_size = fs.data(); out.visited_count = vc.data(); out.dist_cmps = dc.data();
+  const pann_query_params q = to_pann(QP);
+  const uint32_t start = starting_point;
+  pann_check(pann_batch_search(QDI.h, Q_Query_Points.data(), nullptr, nq, Q_Query_Points.get_aligned_bytes(), &start, 1, &q, &out));
+  std::vector<uint32_t> counts(nq);
+  for (size_t i = 0; i < nq; i++) {
+    if (fs[i] < k) {                                                                                  // :416-419
+      std::cout << "Error: for point id " << i << " beam search returned " << fs[i] << " elements, which is less than k = " << k << std::endl;
+      abort();
+    }
+    counts[i] = use_rerank ? (uint32_t)std::min<long>((long)QP.k * QP.rerank_factor, (long)fs[i]) : k;
+    QueryStats.increment_visited((indexType)i, vc[i]);
+    QueryStats.increment_dist((indexType)i, dc[i]);
+  }
+  std::vector<uint32_t> rid(nq * k);
+  std::vector<float> rd(nq * k);
+  pann_check(pann_rerank(DI.h, Query_Points.data(), nq, Query_Points.get_aligned_bytes(), ids.data(), beam, counts.data(), k,
+                         use_rerank ? 1 : 0, rid.data(), rd.data()));
+  std::vector<std::vector<indexType>> all(nq);
+  for (size_t i = 0; i < nq; i++) all[i].assign(rid.begin() + i * k, rid.begin() + (i + 1) * k);
+  if (dists_out) *dists_out = rd;
+  return all;
 }
 
 // range_search(p, G, Points, starting_points, radius, radius_2, QP) -> (result in BFS order, distance comparisons)

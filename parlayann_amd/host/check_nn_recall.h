@@ -12,6 +12,11 @@ namespace parlayANN {
 struct nn_result { double recall; double QPS; long k; long beamQ; double cut; size_t num_queries; long limit;
                    unsigned avg_cmps, tail_cmps, avg_visited, tail_visited; };
 
+// score + report (check_nn_recall.h:83-125) shared by the plain and the quantised-with-rerank searches
+template <class PointRange, typename indexType>
+nn_result report_recall(const std::vector<std::vector<indexType>>& all_ngh, stats<indexType>& QueryStats, PointRange& Query_Points,
+                        const groundTruth<indexType>& GT, long k, const QueryParams& QP, double query_time, bool verbose);
+
 template <class PointRange, typename indexType>
 nn_result checkRecall(DeviceIndex<PointRange, indexType>& DI, PointRange& Query_Points, const groundTruth<indexType>& GT,
                       long start_point, long k, const QueryParams& QP, bool verbose) {
@@ -23,6 +28,29 @@ nn_result checkRecall(DeviceIndex<PointRange, indexType>& DI, PointRange& Query_
   const auto t0 = std::chrono::steady_clock::now();
   auto all_ngh = qsearchAll<PointRange, indexType>(Query_Points, DI, QueryStats, (indexType)start_point, QP);
   const double query_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return report_recall<PointRange, indexType>(all_ngh, QueryStats, Query_Points, GT, k, QP, query_time, verbose);
+}
+
+// checkRecall with a quantised first pass (check_nn_recall.h:51-54: qsearchAll over the three range pairs)
+template <class PointRange, class QPointRange, typename indexType>
+nn_result checkRecall(DeviceIndex<PointRange, indexType>& DI, DeviceIndex<QPointRange, indexType>& QDI, PointRange& Query_Points,
+                      QPointRange& Q_Query_Points, const groundTruth<indexType>& GT, long start_point, long k,
+                      const QueryParams& QP, bool verbose) {
+  if (GT.size() > 0 && k > GT.dimension()) {
+    std::cout << k << "@" << k << " too large for ground truth data of size " << GT.dimension() << std::endl;
+    abort();
+  }
+  stats<indexType> QueryStats(Query_Points.size());
+  const auto t0 = std::chrono::steady_clock::now();
+  auto all_ngh = qsearchAll<PointRange, QPointRange, indexType>(Query_Points, Q_Query_Points, DI, QDI, QueryStats,
+                                                                (indexType)start_point, QP);
+  const double query_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return report_recall<PointRange, indexType>(all_ngh, QueryStats, Query_Points, GT, k, QP, query_time, verbose);
+}
+
+template <class PointRange, typename indexType>
+nn_result report_recall(const std::vector<std::vector<indexType>>& all_ngh, stats<indexType>& QueryStats, PointRange& Query_Points,
+                        const groundTruth<indexType>& GT, long k, const QueryParams& QP, double query_time, bool verbose) {
   double recall = 0.0;
   if (GT.size() > 0) {
     const size_t n = Query_Points.size();

@@ -5,6 +5,7 @@
 // -alpha -num_passes -cluster_size -mst_deg -num_clusters -alg {vamana,hcnng} -device -seed -device_build {1,0}
 // -self 1 -range 1 -radius -radius_2 [-use_existing 1]  (vamana/neighbors.h:86-104)
 // -quantize_bits 8 with -data_type float  (neighborsTime.C:157-164,190-197)
+// -quantize_mode 1 [-rerank_factor 100] with -data_type float  (vamana/neighbors.h:117-147)
 #include <cstring>
 #include <map>
 #include <string>
@@ -59,6 +60,49 @@ int run_quantized(const Args& a) {
     if (a.str("-query_path")) { PointRange<FP> Qf(a.str("-query_path")); auto QQ = quantize_u8(Qf, pm); return run_on<Euclidian_Point<uint8_t>>(a, QP, &QQ); }
     return run_on<Euclidian_Point<uint8_t>>(a, QP, nullptr);
   }
+}
+
+// -quantize_mode 1 (BuildParams::quantize == 1, vamana/neighbors.h:117-147): the index is built on the one-byte
+// points; queries search the one-byte mirror first and the best k * rerank_factor are re-scored on the float mirror
+// (ANN_Quantized -> search_and_parse -> qsearchAll -> beam_search_rerank).  MIPS uses Quantized_Mips_Point<8,true,255>.
+template <bool MIPS>
+int run_quantize_mode(const Args& a) {
+  using FP = typename std::conditional<MIPS, Mips_Point<float>, Euclidian_Point<float>>::type;
+  using QPt = typename std::conditional<MIPS, Mips_Point<int8_t>, Euclidian_Point<uint8_t>>::type;
+  using PR = PointRange<FP>; using QPR = PointRange<QPt>;
+  const char* base = a.str("-base_path");
+  if (!base) { std::cout << "usage: neighbors -base_path <b> ..." << std::endl; return 1; }
+  PR Points(base);
+  std::cout << "quantizing build and first pass of search to 1 byte" << std::endl;
+  float mv = 0; euclid_u8_parameters pm;
+  auto quant = [&](PR& src) -> QPR {
+    if constexpr (MIPS) return quantize_mips_i8(src, mv); else return quantize_u8(src, pm);
+  };
+  if constexpr (MIPS) mv = generate_max_val_mips_i8(Points, true); else pm = generate_parameters_u8(Points);
+  QPR Q_Points = quant(Points);
+  const long k = a.num("-k", 10), Q = a.num("-Q", 64);
+  BuildParams BP(a.num("-R", 64), a.num("-L", 128), a.flt("-alpha", 1.2), (int)a.num("-num_passes", 1));
+  Graph<indexType> G;
+  if (a.str("-graph_path")) {
+    G = Graph<indexType>(a.str("-graph_path"));
+  } else {
+    G = Graph<indexType>(BP.max_degree(), Points.size());
+    knn_index<QPR, indexType> I(BP); I.seed = (uint64_t)a.num("-seed", 1);
+    stats<indexType> BuildStats(Points.size());
+    I.build_index(G, Q_Points, BuildStats);
+    if (a.str("-graph_outfile")) G.save(a.str("-graph_outfile"));
+  }
+  if (a.str("-query_path")) {
+    PR Queries(a.str("-query_path"));
+    QPR Q_Queries = quant(Queries);
+    groundTruth<indexType> GT(a.str("-gt_path"));
+    DeviceIndex<PR, indexType> DI(Points, &G, 0, (int)a.num("-device", 0));
+    DeviceIndex<QPR, indexType> QDI(Q_Points, &G, 0, (int)a.num("-device", 0));
+    QueryParams QP(k, Q, 1.35, (long)G.size(), (long)G.max_degree());
+    QP.rerank_factor = a.num("-rerank_factor", 100);
+    for (int rep = 0; rep < 5; rep++) checkRecall<PR, QPR, indexType>(DI, QDI, Queries, Q_Queries, GT, 0, k, QP, true);
+  }
+  return 0;
 }
 
 template <class Point>
@@ -132,6 +176,8 @@ int main(int argc, char** argv) {
   const bool mips = df == "mips";
   if (dt == "uint8") return mips ? run<Mips_Point<uint8_t>>(a) : run<Euclidian_Point<uint8_t>>(a);
   if (dt == "int8") return mips ? run<Mips_Point<int8_t>>(a) : run<Euclidian_Point<int8_t>>(a);
+  if (a.num("-quantize_mode", 0) == 1 && dt == "float") return mips ? run_quantize_mode<true>(a) : run_quantize_mode<false>(a);
+  if (a.num("-quantize_mode", 0) != 0) { std::cout << "Error: -quantize_mode 1 (one-level) with -data_type float is the mode mirrored here" << std::endl; abort(); }
   const long qbits = a.num("-quantize_bits", 0);
   if (dt == "float" && qbits == 8) return mips ? run_quantized<true>(a) : run_quantized<false>(a);
   if (qbits != 0) { std::cout << "Error: -quantize_bits supports 8 with -data_type float (16 is not mirrored)" << std::endl; abort(); }

@@ -133,6 +133,44 @@ def test_cli_quantize_bits_8(exe, tmp_path, oracle, dist):
     assert abs(rec - oracle.recall(o["ids"], gt, gd, 10)) < 1e-6 and rec > 0.8
 
 
+@pytest.mark.parametrize("dist", ["Euclidian", "mips"])
+def test_cli_quantize_mode_1_rerank(exe, tmp_path, oracle, dist):
+    """-quantize_mode 1 (vamana/neighbors.h:117-147): build + first search pass on one-byte points, re-score the best
+    k * rerank_factor on the float points (beam_search_rerank, beamSearch.h:390-454).  Expected values from the
+    oracle: search on the quantised data, exact float distances of the frontier prefix, sort by (dist,id), keep k."""
+    n, nq, k, beam, rf = 6000, 200, 10, 64, 3
+    if dist == "Euclidian":
+        X, Q = datasets.deep_like(n, 96, seed=1234) * 3.0 - 0.2, datasets.deep_like(nq, 96, seed=4321) * 3.0 - 0.2
+        slope, off = oracle.euclid_u8_params(X)
+        Xq, Qq, metric = oracle.euclid_u8_translate(X, slope, off), oracle.euclid_u8_translate(Q, slope, off), "l2"
+    else:
+        X, Q = datasets.t2i_like(n, 100, seed=1234), datasets.t2i_like(nq, 100, seed=4321)
+        mv = oracle.mips_i8_maxval(X, trim=True)
+        Xq, Qq, metric = oracle.mips_i8_translate(X, mv), oracle.mips_i8_translate(Q, mv), "mips"
+    X, Q = X.astype(np.float32), Q.astype(np.float32)
+    gt, gd = oracle.bruteforce_knn(X, Q, 100, metric)
+    io.write_bin(tmp_path / "b.fbin", X); io.write_bin(tmp_path / "q.fbin", Q); io.write_ibin(tmp_path / "gt.ibin", gt, gd)
+    alpha = 1.2 if dist == "Euclidian" else 1.0
+    out = _run(exe, "-base_path", tmp_path / "b.fbin", "-query_path", tmp_path / "q.fbin", "-gt_path", tmp_path / "gt.ibin",
+               "-graph_outfile", tmp_path / "g.graph", "-data_type", "float", "-dist_func", dist, "-quantize_mode", 1,
+               "-rerank_factor", rf, "-R", 32, "-L", 64, "-alpha", alpha, "-k", k, "-Q", beam, "-seed", 5)
+    assert "quantizing build and first pass of search to 1 byte" in out
+    Go, _ = oracle.vamana_build(Xq, 32, 64, alpha, num_passes=1, seed=5, metric=metric)
+    G = io.read_graph(tmp_path / "g.graph")
+    np.testing.assert_array_equal(G[:, 0], Go[:, 0])
+    o = oracle.batch_search(Xq, Go, queries=Qq, k=k, beam=beam, metric=metric, out_k=beam)
+    want = np.empty((nq, k), np.uint32)
+    for i in range(nq):
+        c = int(min(k * rf, o["frontier_size"][i]))
+        ids = o["ids"][i, :c]
+        d = np.array([oracle.distance(X[j], Q[i], metric) for j in ids], np.float32)
+        want[i] = ids[np.lexsort((ids, d))][:k]
+    rec = float(re.findall(r"recall=([0-9.]+)", out)[0])
+    assert abs(rec - oracle.recall(want, gt, gd, k)) < 1e-6 and rec > 0.8
+    vis = int(re.findall(r"visited=([0-9]+)", out)[0])
+    assert vis == int(o["visited_count"].astype(np.uint64).sum() // nq)
+
+
 def test_pivot_split_matches_oracle_distances(oracle):
     X = datasets.sift_like(3000, 96, seed=1, dtype=np.float32)
     ix = DeviceIndex(X, max_degree=8)
