@@ -80,7 +80,7 @@ int run_quantize_mode(const Args& a) {
   };
   if constexpr (MIPS) mv = generate_max_val_mips_i8(Points, true); else pm = generate_parameters_u8(Points);
   QPR Q_Points = quant(Points);
-  const long k = a.num("-k", 10), Q = a.num("-Q", 64);
+  const long k = a.num("-k", 10), Q = a.num("-Q", 0);
   BuildParams BP(a.num("-R", 64), a.num("-L", 128), a.flt("-alpha", 1.2), (int)a.num("-num_passes", 1));
   Graph<indexType> G;
   if (a.str("-graph_path")) {
@@ -98,9 +98,8 @@ int run_quantize_mode(const Args& a) {
     groundTruth<indexType> GT(a.str("-gt_path"));
     DeviceIndex<PR, indexType> DI(Points, &G, 0, (int)a.num("-device", 0));
     DeviceIndex<QPR, indexType> QDI(Q_Points, &G, 0, (int)a.num("-device", 0));
-    QueryParams QP(k, Q, 1.35, (long)G.size(), (long)G.max_degree());
-    QP.rerank_factor = a.num("-rerank_factor", 100);
-    for (int rep = 0; rep < 5; rep++) checkRecall<PR, QPR, indexType>(DI, QDI, Queries, Q_Queries, GT, 0, k, QP, true);
+    search_and_parse([&](const QueryParams& QP) { return checkRecall<PR, QPR, indexType>(DI, QDI, Queries, Q_Queries, GT, 0, k == 0 ? 10 : k, QP, Q != 0 || a.num("-verbose", 0)); },
+                     G.size(), (long)G.max_degree(), k, Q, (int)a.num("-rerank_factor", 100));
   }
   return 0;
 }
@@ -109,7 +108,7 @@ template <class Point>
 int run_on(const Args& a, PointRange<Point>& Points, PointRange<Point>* QueriesIn) {
   using PR = PointRange<Point>;
   const std::string alg = a.str("-alg") ? a.str("-alg") : "vamana";
-  const long k = a.num("-k", 10), Q = a.num("-Q", 64);
+  const long k = a.num("-k", 10), Q = a.num("-Q", 0);            // 0: sweep (neighborsTime.C: -Q default 0)
   BuildParams BP;
   if (alg == "hcnng") BP = BuildParams(a.num("-num_clusters", 30), a.num("-cluster_size", 1000), a.num("-mst_deg", 3));
   else BP = BuildParams(a.num("-R", 64), a.num("-L", 128), a.flt("-alpha", 1.2), (int)a.num("-num_passes", 1));
@@ -139,8 +138,9 @@ int run_on(const Args& a, PointRange<Point>& Points, PointRange<Point>* QueriesI
     PR& Queries = *QueriesIn;
     groundTruth<indexType> GT(a.str("-gt_path"));
     DeviceIndex<PR, indexType> DI(Points, &G, 0, (int)a.num("-device", 0));
-    QueryParams QP(k, Q, 1.35, (long)G.size(), (long)G.max_degree());   // check_nn_recall.h:219,224
-    for (int rep = 0; rep < 5; rep++) checkRecall<PR, indexType>(DI, Queries, GT, 0, k, QP, true);   // :221-226
+    // -Q given: five repetitions at that beam (:224-229); otherwise the reference's sweep + recall-bucket table
+    search_and_parse([&](const QueryParams& QP) { return checkRecall<PR, indexType>(DI, Queries, GT, 0, k == 0 ? 10 : k, QP, Q != 0 || a.num("-verbose", 0)); },
+                     G.size(), (long)G.max_degree(), k, Q);
   } else if (a.num("-self", 0) && a.num("-range", 0)) {
     // vamana/neighbors.h:86-104: every base point range-searches from its own vertex.  same_as() skips that
     // start, so upstream reports 0 edges here; `-use_existing 1` seeds with the point's out-neighbours instead

@@ -171,6 +171,30 @@ def test_cli_quantize_mode_1_rerank(exe, tmp_path, oracle, dist):
     assert vis == int(o["visited_count"].astype(np.uint64).sum() // nq)
 
 
+def test_cli_default_is_the_reference_sweep(exe, files, oracle):
+    """without -Q the CLI runs search_and_parse (check_nn_recall.h:181-268): 43 beams, 20 visit limits, the
+    "best accuracy" point, then one line per recall bucket (parse_results.h:192-218)"""
+    d, X, Q, gt, gd = files
+    _run(exe, "-base_path", d / "base.bin", "-graph_outfile", d / "s.graph", "-data_type", "uint8", "-R", 32, "-L", 64, "-seed", 5)
+    out = _run(exe, "-base_path", d / "base.bin", "-query_path", d / "query.bin", "-gt_path", d / "gt.ibin", "-graph_path", d / "s.graph",
+               "-data_type", "uint8", "-k", 10, "-verbose", 1)
+    G = io.read_graph(d / "s.graph")
+    lines = re.findall(r"search: Q=(\d+), k=(\d+), limit=(\d+), recall=([0-9.e-]+), visited=(\d+), comparisons=(\d+)", out)
+    assert len(lines) == 43 + 20 + 1
+    by = {(int(q), int(kk), int(lim)): (float(rec), int(v), int(c)) for q, kk, lim, rec, v, c in lines}
+    n = len(X)
+    for (beam, kk, lim, dl, cut) in ((10, 10, n, 32, 1.35), (70, 10, n, 32, 1.35), (500, 10, n, 32, 1.35), (20, 10, 20, 32, 1.35),
+                                     (35, 10, 35, 32, 1.35), (1000, 100, n, 32, 10.0)):
+        o = oracle.batch_search(X, G, queries=Q, k=kk, beam=beam, cut=cut, limit=lim, degree_limit=dl)
+        rec, vis, cm = by[(beam, kk, lim)]
+        assert abs(rec - oracle.recall(o["ids"][:, :10], gt, gd, 10)) < 1e-5, (beam, kk, lim)
+        assert vis == int(o["visited_count"].astype(np.uint64).sum() // len(Q)) and cm == int(o["dist_cmps"].astype(np.uint64).sum() // len(Q))
+    table = re.findall(r"For 10@10 recall = ([0-9.e-]+), QPS = ([0-9.e+]+), Q = (\d+)", out)
+    assert len(table) >= 3
+    recs = [float(t[0]) for t in table]
+    assert recs == sorted(recs)                      # one best-QPS line per bucket, buckets ascending
+
+
 def test_pivot_split_matches_oracle_distances(oracle):
     X = datasets.sift_like(3000, 96, seed=1, dtype=np.float32)
     ix = DeviceIndex(X, max_degree=8)
