@@ -195,6 +195,19 @@ def test_cli_default_is_the_reference_sweep(exe, files, oracle):
     assert recs == sorted(recs)                      # one best-QPS line per bucket, buckets ascending
 
 
+def test_compute_groundtruth_cli(exe, files, oracle):
+    """data_tools/compute_groundtruth.cpp over the C-ABI: the .ibin it writes equals the oracle's brute force"""
+    d, X, Q, gt, gd = files
+    tool = os.path.join(HOST, "compute_groundtruth")
+    out = subprocess.run([tool, "-base_path", str(d / "base.bin"), "-query_path", str(d / "query.bin"), "-data_type", "uint8",
+                          "-dist_func", "Euclidian", "-k", "100", "-gt_path", str(d / "gt2.ibin")], check=True, capture_output=True,
+                         text=True).stdout
+    assert "Computing the 100 nearest neighbors" in out
+    ids, dists = io.read_ibin(d / "gt2.ibin")
+    np.testing.assert_array_equal(ids, gt)
+    np.testing.assert_array_equal(dists, gd)
+
+
 def test_pivot_split_matches_oracle_distances(oracle):
     X = datasets.sift_like(3000, 96, seed=1, dtype=np.float32)
     ix = DeviceIndex(X, max_degree=8)
