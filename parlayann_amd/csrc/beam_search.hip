@@ -885,6 +885,10 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
 // the reference's own row alignment, point_range.h:94) or LPC=16 for long rows.
 void choose_point_layout(uint32_t dbytes, uint32_t* lpc, uint32_t* nch) {
   const uint32_t r64 = (dbytes + 63) / 64 * 64;
+  if (const char* f = getenv("PANN_FORCE_LPC")) {          // diagnostic A/B switch: lanes per candidate 4 / 8 / 16
+    const uint32_t l = (uint32_t)atoi(f);
+    if ((l == 4 || l == 8 || l == 16) && r64 % (l * 16) == 0 && r64 / (l * 16) > 1) { *lpc = l; *nch = r64 / (l * 16); return; }
+  }
   if (r64 == 128) { *lpc = 8; *nch = 1; return; }
   if (r64 == 256) { *lpc = 16; *nch = 1; return; }
   if (r64 == 512) { *lpc = 32; *nch = 1; return; }
@@ -915,7 +919,7 @@ static Plan make_plan(const DeviceIndex& ix, const SearchArgs& a) {
   // at merge time |C| <= (beam/8 - 1) + deg_eff (accumulation stops at beam/8); starts first
   p.ccap = (std::max<uint32_t>(beam / 8 + p.deg_eff, a.nstarts) + 63) / 64 * 64;
   p.dcap = 256;
-  const bool nch1 = (ix.nch == 1);
+  const bool nch1 = layout_query_in_registers(ix);
   size_t fixed = (size_t)p.bcap * 8 * 2 + (size_t)p.ccap * 8 + (size_t)p.bcap * 2 +
                  (size_t)p.ccap * 2 + (nch1 ? 0 : (size_t)ix.nch * ix.lpc * 16);
   size_t hbytes = (size_t)4 << p.bits;
@@ -989,7 +993,7 @@ static hipError_t launch_variant(const BSParams& P, const Plan& p, hipStream_t s
 
 template <int DT, int METRIC>
 static hipError_t launch_layout(const DeviceIndex& ix, const BSParams& P, const Plan& p, hipStream_t s) {
-  if (ix.nch == 1) {
+  if (layout_query_in_registers(ix)) {
     if (ix.lpc == 8) return launch_variant<DT, METRIC, 8, true>(P, p, s);
     if (ix.lpc == 16) return launch_variant<DT, METRIC, 16, true>(P, p, s);
     if (ix.lpc == 32) return launch_variant<DT, METRIC, 32, true>(P, p, s);

@@ -569,7 +569,7 @@ int query_distances_dev(const DeviceIndex& ix, hipStream_t st, const uint8_t* d_
                         float* d_out) {
   if (nq == 0) return PANN_OK;
   const PointsView pv{ix.points, ix.pstride, ix.nch, ix.exact};
-  const size_t qb = ix.nch == 1 ? 0 : (size_t)ix.nch * ix.lpc * 16;
+  const size_t qb = query_lds_bytes(ix);
 #define CALL_QD(DT, MT, L, N1) hipLaunchKernelGGL((query_distances_kernel<DT, MT, L, N1>), dim3((uint32_t)nq), dim3(PANN_WAVE), qb, st, pv, ix.dbytes, d_q_ext, q_stride, d_q_ids, d_ids, m, paired, d_out)
   PANN_TYPE_SWITCH(ix, CALL_QD);
 #undef CALL_QD
@@ -611,7 +611,7 @@ int pivot_split_dev(const DeviceIndex& ix, hipStream_t st, const uint32_t* d_ids
                     const uint32_t* d_pb, uint8_t* d_side) {
   if (ntiles == 0) return PANN_OK;
   const PointsView pv{ix.points, ix.pstride, ix.nch, ix.exact};
-  const size_t qb = ix.nch == 1 ? 0 : (size_t)ix.nch * ix.lpc * 16;
+  const size_t qb = query_lds_bytes(ix);
 #define CALL_PS(DT, MT, L, N1) hipLaunchKernelGGL((pivot_split_kernel<DT, MT, L, N1>), dim3(ntiles), dim3(PANN_WAVE), qb, st, pv, ix.dbytes, d_ids, d_tile_seg, d_tile_lo, d_tile_cnt, d_pa, d_pb, d_side)
   PANN_TYPE_SWITCH(ix, CALL_PS);
 #undef CALL_PS
@@ -663,7 +663,7 @@ int rerank_dev(const DeviceIndex& ix, hipStream_t st, const uint8_t* d_q, uint64
   if (nq == 0) return PANN_OK;
   if (c == 0 || c > 4096) { set_error("pann_rerank: candidates per query must be in [1,4096]"); return PANN_ERR_BAD_ARG; }
   const PointsView pv{ix.points, ix.pstride, ix.nch, ix.exact};
-  const size_t lds = (size_t)((c + 1) & ~1u) * 8 + (ix.nch == 1 ? 0 : (size_t)ix.nch * ix.lpc * 16);
+  const size_t lds = (size_t)((c + 1) & ~1u) * 8 + query_lds_bytes(ix);
 #define CALL_RR(DT, MT, L, N1) hipLaunchKernelGGL((rerank_kernel<DT, MT, L, N1>), dim3((uint32_t)nq), dim3(PANN_WAVE), lds, st, pv, ix.dbytes, d_q, q_stride, d_cand, c, d_cnt, k, resort, d_out_ids, d_out_dists)
   PANN_TYPE_SWITCH(ix, CALL_RR);
 #undef CALL_RR

@@ -294,7 +294,7 @@ int hcnng_build_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, uint32
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto secs = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
   const PointsView pv{ix.points, ix.pstride, ix.nch, ix.exact};
-  const size_t qb = ix.nch == 1 ? 0 : (size_t)ix.nch * ix.lpc * 16;
+  const size_t qb = query_lds_bytes(ix);
   const uint32_t nb256 = (uint32_t)((n + 255) / 256);
 
   HBuf b_ids, b_new, b_first, b_scan, b_pos, b_deg, b_leaflo, b_nnids, b_nnd, b_ka, b_kb, b_par, b_rnk, b_dgr, b_tmp;

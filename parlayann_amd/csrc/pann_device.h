@@ -352,6 +352,71 @@ __device__ __forceinline__ void gather_tile(const PointsView& PV, const QReg<DT>
   if (s0 < m) gather_span<DT, METRIC, LPC, NCH1, U>(PV, qreg, qlds, Pl, m, s0, lane, emit);
 }
 
+// gather_tile for B query vectors at once: every candidate vector is fetched ONCE and scored against all of
+// them (robustPrune with several speculative picks per pass).  Query b: qreg[b] when the row is one chunk per
+// lane, else qlds[b * qstride4 ...].  Per (query, candidate) the arithmetic is exactly gather_tile's.
+// emit(has, ci, id, d[B]) is called by all lanes; `has` on the first lane of each candidate group.
+template <int DT, int METRIC, int LPC, bool NCH1, int B, typename Emit>
+__device__ __forceinline__ void gather_tile_multi(const PointsView& PV, const QReg<DT> (&qreg)[B], const uint4* qlds,
+                                                  uint32_t qstride4, const uint32_t* Pl, uint32_t m, int lane, Emit&& emit) {
+  constexpr int G = PANN_WAVE / LPC;
+  constexpr int U = NCH1 ? 2 : 1;
+  const int grp = lane / LPC, sub = lane % LPC;
+  for (uint32_t s0 = 0; s0 < m; s0 += G * U) {
+    Acc<DT> acc[B][U];
+    uint32_t ids[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) ids[u] = Pl[min(s0 + u * G + grp, m - 1)];
+#pragma unroll
+    for (int b = 0; b < B; b++)
+#pragma unroll
+      for (int u = 0; u < U; u++) acc[b][u].clear();
+    if constexpr (NCH1) {
+      uint4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        v[u] = *reinterpret_cast<const uint4*>(PV.points + (uint64_t)ids[u] * PV.pstride + sub * 16);
+#pragma unroll
+      for (int b = 0; b < B; b++)
+#pragma unroll
+        for (int u = 0; u < U; u++) dist_accum<DT, METRIC>(acc[b][u], v[u], qreg[b]);
+    } else {
+      constexpr int CB = 3;
+      const uint8_t* rp[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) rp[u] = PV.points + (uint64_t)ids[u] * PV.pstride + sub * 16;
+      for (uint32_t ch0 = 0; ch0 < PV.nch; ch0 += CB) {
+        uint4 v[CB][U];
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++) {
+          const uint32_t chx = min(ch0 + cb, PV.nch - 1);
+#pragma unroll
+          for (int u = 0; u < U; u++) v[cb][u] = *reinterpret_cast<const uint4*>(rp[u] + chx * (LPC * 16));
+        }
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++) {
+          if (ch0 + cb < PV.nch) {
+#pragma unroll
+            for (int b = 0; b < B; b++) {
+              const QReg<DT> qv = make_qreg<DT>(qlds[b * qstride4 + (ch0 + cb) * LPC + sub]);
+#pragma unroll
+              for (int u = 0; u < U; u++) dist_accum<DT, METRIC>(acc[b][u], v[cb][u], qv);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      float d[B];
+#pragma unroll
+      for (int b = 0; b < B; b++) d[b] = dist_finish<DT, METRIC>(group_sum<LPC>(acc_lane_value<DT, METRIC>(acc[b][u])));
+      const uint32_t ci = s0 + u * G + grp;
+      emit((sub == 0) && (ci < m), ci, ids[u], d);
+    }
+  }
+}
+
 // load one row (device layout, or an external query row of `valid` bytes) as the wave's query:
 // registers when NCH1, else LDS qlds[nch*LPC].  Caller syncs before using qlds.
 template <int DT, int LPC, bool NCH1>

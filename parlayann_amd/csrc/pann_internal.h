@@ -32,6 +32,12 @@ struct DeviceIndex {
   uint32_t gstride = 0;  // uint32 per graph row on the device
 };
 
+// The kernels come in two families (PANN_LAYOUT_SWITCH): rows that are ONE 16-byte chunk per lane with 8 / 16 / 32
+// lanes per candidate keep the query in registers; every other layout -- including 64-byte rows, lpc 4 / nch 1 --
+// runs the generic variants, which keep the query in LDS.  All LDS sizes on the host must use THIS predicate.
+inline bool layout_query_in_registers(const DeviceIndex& ix) { return ix.nch == 1 && ix.lpc != 4; }
+inline size_t query_lds_bytes(const DeviceIndex& ix) { return layout_query_in_registers(ix) ? 0 : (size_t)ix.nch * ix.lpc * 16; }
+
 struct SearchArgs {  // one batched beam search, everything device resident
   const uint8_t* queries; uint64_t qstride;  // external queries (or null)
   const uint32_t* query_ids;                 // base-point queries (or null)

@@ -209,7 +209,7 @@ int range_search_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, const
   A.radius_2 = radius_2; A.cap = cap;
   A.table = (unsigned long long*)ws.buf; A.hsize = hsize;
   A.out_ids = d_out_ids; A.out_counts = d_out_counts; A.out_cmps = d_out_cmps; A.out_trunc = d_out_trunc;
-  const size_t lds = ix.nch == 1 ? 0 : (size_t)ix.nch * ix.lpc * 16;
+  const size_t lds = query_lds_bytes(ix);
 #define CALL_RS(DT, MT, L, N1) hipLaunchKernelGGL((range_search_kernel<DT, MT, L, N1>), dim3((uint32_t)waves), dim3(PANN_WAVE), lds, st, A)
   PANN_TYPE_SWITCH(ix, CALL_RS);
 #undef CALL_RS

@@ -102,6 +102,8 @@ struct GreedyArgs {
   uint32_t* graph; uint32_t gstride;          // direct write of the owner's row when rows_out == null
   uint32_t* dcmps;
   uint32_t m;
+  uint32_t kcap;                              // lists up to this many keys are pruned in LDS
+  uint32_t single_pick;                       // diagnostic (PANN_PRUNE_SINGLE): bit 0 one pick per pass, bit 1 lists in HBM
 };
 
 __device__ __forceinline__ uint64_t ld_key(const uint64_t* p) {
@@ -111,7 +113,10 @@ __device__ __forceinline__ void st_key(uint64_t* p, uint64_t v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// greedy alpha-prune over the sorted, de-duplicated candidate list (:90-116)
+// greedy alpha-prune over the sorted, de-duplicated candidate list (:90-116).  One wave per owner.  The list
+// (<= A.kcap keys: visited + out-neighbours of one insert) lives in LDS for the whole loop: the sequential
+// walk over picks and the kill flags then cost no HBM round trip; per pick only the pick's vector and the
+// gathered vectors of the live candidates are fetched.  Longer lists (heavy re-prunes) walk the HBM copy.
 template <int DT, int METRIC, int LPC, bool NCH1>
 __global__ void __launch_bounds__(PANN_WAVE) prune_greedy_kernel(GreedyArgs A) {
   const int lane = threadIdx.x;
@@ -119,62 +124,172 @@ __global__ void __launch_bounds__(PANN_WAVE) prune_greedy_kernel(GreedyArgs A) {
   __shared__ uint32_t Pl[PANN_WAVE];    // live candidate ids of the current tile
   __shared__ uint32_t Pp[PANN_WAVE];    // their positions in the segment
   __shared__ float Pd[PANN_WAVE];       // their distance to p  (dist_pprime)
-  __shared__ uint32_t Out[1024];        // selected neighbours (R <= 1024)
   extern __shared__ __align__(16) uint8_t smem[];
   uint4* qlds = reinterpret_cast<uint4*>(smem);
+  uint32_t* Out = reinterpret_cast<uint32_t*>(qlds + (NCH1 ? 0 : 4 * A.pv.nch * LPC)); // [R rounded to 4] selected neighbours (after 4 query slots)
+  uint64_t* Ks = reinterpret_cast<uint64_t*>(Out + ((A.R + 3) & ~3u));                   // [kcap] the list, when it fits
   const uint32_t p = A.owners[oi];
   uint64_t* K = A.keys + A.seg_begin[oi];
   const uint32_t n = A.seg_end[oi] - A.seg_begin[oi];
+  const bool in_lds = n <= A.kcap && !(A.single_pick & 2u);
+  auto ldk = [&](uint32_t i) -> uint64_t { return in_lds ? Ks[i] : ld_key(K + i); };
+  auto stk = [&](uint32_t i, uint64_t v) { if (in_lds) Ks[i] = v; else st_key(K + i, v); };
 
   // std::unique by id (:86-88): after the sort equal ids are adjacent (same id => same key)
   uint32_t carry = SENTINEL;   // original id of the last entry of the previous tile
   for (uint32_t i0 = 0; i0 < n; i0 += PANN_WAVE) {
     const uint32_t i = i0 + lane;
-    const uint64_t k = i < n ? K[i] : KEY_INF;
+    uint64_t k = i < n ? K[i] : KEY_INF;
     const uint32_t myid = key_id(k);
     uint32_t previd = __shfl_up(myid, 1);
     if (lane == 0) previd = carry;
     carry = __shfl(myid, PANN_WAVE - 1);
-    if (i < n && myid == previd) st_key(K + i, (k & 0xFFFFFFFF00000000ull) | SENTINEL);
+    if (i < n && myid == previd) k = (k & 0xFFFFFFFF00000000ull) | SENTINEL;
+    if (i < n) stk(i, k);
   }
-  __builtin_amdgcn_s_waitcnt(0);
+  if (!in_lds) __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
 
   uint32_t nsel = 0, dc = 0;
-  for (uint32_t idx = 0; idx < n && nsel < A.R; idx++) {
-    const uint32_t ps = key_id(ld_key(K + idx));
-    if (ps == p || ps == SENTINEL) continue;        // :99
-    if (lane == 0) Out[nsel] = ps;                  // :103
-    nsel++;
-    if (nsel == A.R) break;                          // the inner loop's kills can no longer matter
-    QReg<DT> qreg{};
-    __syncthreads();
-    load_query<DT, LPC, NCH1>(A.pv.points + (uint64_t)ps * A.pv.pstride, A.dbytes, A.pv.nch, qreg, qlds, lane);
-    __syncthreads();
-    for (uint32_t t0 = idx + 1; t0 < n; t0 += PANN_WAVE) {   // :105-115, 64 candidates at a time
-      const uint32_t i = t0 + lane;
-      uint64_t k = KEY_INF;
-      if (i < n) k = ld_key(K + i);
-      const bool live = (i < n) && (key_id(k) != SENTINEL);
-      const uint64_t lm = __ballot(live);
-      const uint32_t mm = __popcll(lm);
-      if (mm == 0) continue;
-      if (live) { const uint32_t at = lanes_below(lm, lane); Pl[at] = key_id(k); Pp[at] = i; Pd[at] = key_dist(k); }
-      dc += mm;
+  // Several picks per pass.  The next PB live entries are taken as speculative picks: their vectors are loaded
+  // together and every live candidate vector is fetched once and scored against all of them; the sequential
+  // semantics (a pick killed by an earlier pick of the same pass is not a pick; a candidate is counted for and
+  // killed by the selected picks in order) are then resolved from those distances -- a quarter of the dependent
+  // memory round trips of one-pick-at-a-time.  Lists in HBM and the exact-float-order mode keep the plain loop.
+  constexpr int PB = 4;
+  __shared__ float Dd[PB][PANN_WAVE];
+  const uint32_t qstride4 = NCH1 ? 0u : A.pv.nch * LPC;
+  if (in_lds && !A.pv.exact && !(A.single_pick & 1u)) {
+    uint32_t idx = 0;
+    while (idx < n && nsel < A.R) {
+      const uint32_t wi = idx + lane;
+      const uint32_t idw = wi < n ? key_id(Ks[wi]) : SENTINEL;
+      uint64_t pm = __ballot(idw != SENTINEL && idw != p);                 // :99
+      if (pm == 0ull) { idx += PANN_WAVE; continue; }
+      uint32_t ppos[PB], pid[PB];
+      int nb = 0;
+      const int room = (int)min((uint32_t)PB, A.R - nsel);
+#pragma unroll
+      for (int b = 0; b < PB; b++) {
+        ppos[b] = 0; pid[b] = 0;
+        if (b < room && pm) {
+          const int L = __ffsll((unsigned long long)pm) - 1;
+          pm &= pm - 1;
+          ppos[b] = idx + (uint32_t)L; pid[b] = (uint32_t)__builtin_amdgcn_readlane((int)idw, L); nb = b + 1;
+        }
+      }
+      QReg<DT> qreg[PB];
       __syncthreads();
-      gather_tile<DT, METRIC, LPC, NCH1, 4>(A.pv, qreg, qlds, Pl, mm, lane,
-        [&](bool has, uint32_t ci, uint32_t, float d_sp) {
-          if (has) {
-            const float d_pp = Pd[ci];
-            if (A.alpha * (double)d_sp <= (double)d_pp)       // :111
-              st_key(K + Pp[ci], ((uint64_t)f2ord(d_pp) << 32) | SENTINEL);   // candidates[i].first = -1
+#pragma unroll
+      for (int b = 0; b < PB; b++) {
+        const uint32_t src = pid[b < nb ? b : 0];                            // unused slots re-read pick 0 (uniform code)
+        load_query<DT, LPC, NCH1>(A.pv.points + (uint64_t)src * A.pv.pstride, A.dbytes, A.pv.nch, qreg[b], qlds + b * qstride4, lane);
+      }
+      __syncthreads();
+      bool sel[PB] = {false, false, false, false}, kills[PB] = {false, false, false, false};
+      bool first_tile = true;
+      const uint32_t nsel0 = nsel;
+      for (uint32_t t0 = ppos[0] + 1; t0 < n; t0 += PANN_WAVE) {             // :105-115
+        const uint32_t i = t0 + lane;
+        const uint64_t k = i < n ? Ks[i] : KEY_INF;
+        const bool live = (i < n) && (key_id(k) != SENTINEL);
+        const uint64_t lm = __ballot(live);
+        const uint32_t mm = __popcll(lm);
+        if (mm == 0) continue;
+        if (live) { const uint32_t at = lanes_below(lm, lane); Pl[at] = key_id(k); Pp[at] = i; Pd[at] = key_dist(k); }
+        __syncthreads();
+        gather_tile_multi<DT, METRIC, LPC, NCH1, PB>(A.pv, qreg, qlds, qstride4, Pl, mm, lane,
+          [&](bool has, uint32_t ci, uint32_t, const float (&d)[PB]) {
+            if (has) {
+#pragma unroll
+              for (int b = 0; b < PB; b++) Dd[b][ci] = d[b];
+            }
+          });
+        __syncthreads();
+        const bool me = lane < (int)mm;
+        const uint32_t mypos = me ? Pp[lane] : 0u;
+        const float dpp = me ? Pd[lane] : 0.0f;
+        float dl[PB];
+#pragma unroll
+        for (int b = 0; b < PB; b++) dl[b] = Dd[b][lane];
+        if (first_tile) {   // which of the speculative picks survive the earlier ones; all of them sit in this tile
+          first_tile = false;
+          sel[0] = true; nsel++; kills[0] = nsel < A.R;                      // the R-th pick runs no inner loop
+          bool stop = nsel == A.R;
+#pragma unroll
+          for (int j = 1; j < PB; j++) {
+            if (j < nb && !stop) {
+              const int Lj = __ffsll((unsigned long long)__ballot(me && mypos == ppos[j])) - 1;
+              const float dppj = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(dpp), Lj));
+              bool dead = false;
+#pragma unroll
+              for (int i2 = 0; i2 < j; i2++) {
+                if (kills[i2]) {
+                  const float dij = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(dl[i2]), Lj));
+                  dead = dead || (A.alpha * (double)dij <= (double)dppj);   // :111
+                }
+              }
+              if (!dead) { sel[j] = true; nsel++; kills[j] = nsel < A.R; stop = nsel == A.R; }
+            }
           }
-        });
-      __syncthreads();
+        }
+        bool alive = me;
+#pragma unroll
+        for (int j = 0; j < PB; j++) {
+          if (kills[j]) {
+            const bool elig = alive && mypos > ppos[j];
+            dc += (uint32_t)__popcll(__ballot(elig));                        // distance_comps of pick j's inner loop
+            if (elig && A.alpha * (double)dl[j] <= (double)dpp) alive = false;
+          }
+        }
+        if (me && !alive) Ks[mypos] = ((uint64_t)f2ord(dpp) << 32) | SENTINEL;   // candidates[i].first = -1
+        __syncthreads();
+      }
+      if (first_tile) { sel[0] = true; nsel++; }                             // nothing live after the pick
+      if (lane == 0) {
+        uint32_t at = nsel0;
+#pragma unroll
+        for (int j = 0; j < PB; j++) if (sel[j]) Out[at++] = pid[j];         // :103
+      }
+      idx = ppos[nb - 1] + 1;
     }
-    __builtin_amdgcn_s_waitcnt(0);
+  } else {
+    for (uint32_t idx = 0; idx < n && nsel < A.R; idx++) {
+      const uint32_t ps = key_id(ldk(idx));
+      if (ps == p || ps == SENTINEL) continue;        // :99
+      if (lane == 0) Out[nsel] = ps;                  // :103
+      nsel++;
+      if (nsel == A.R) break;                          // the inner loop's kills can no longer matter
+      QReg<DT> qreg{};
+      __syncthreads();
+      load_query<DT, LPC, NCH1>(A.pv.points + (uint64_t)ps * A.pv.pstride, A.dbytes, A.pv.nch, qreg, qlds, lane);
+      __syncthreads();
+      for (uint32_t t0 = idx + 1; t0 < n; t0 += PANN_WAVE) {   // :105-115, 64 candidates at a time
+        const uint32_t i = t0 + lane;
+        uint64_t k = KEY_INF;
+        if (i < n) k = ldk(i);
+        const bool live = (i < n) && (key_id(k) != SENTINEL);
+        const uint64_t lm = __ballot(live);
+        const uint32_t mm = __popcll(lm);
+        if (mm == 0) continue;
+        if (live) { const uint32_t at = lanes_below(lm, lane); Pl[at] = key_id(k); Pp[at] = i; Pd[at] = key_dist(k); }
+        dc += mm;
+        __syncthreads();
+        gather_tile<DT, METRIC, LPC, NCH1, 4>(A.pv, qreg, qlds, Pl, mm, lane,
+          [&](bool has, uint32_t ci, uint32_t, float d_sp) {
+            if (has) {
+              const float d_pp = Pd[ci];
+              if (A.alpha * (double)d_sp <= (double)d_pp)       // :111
+                stk(Pp[ci], ((uint64_t)f2ord(d_pp) << 32) | SENTINEL);   // candidates[i].first = -1
+            }
+          });
+        __syncthreads();
+      }
+      if (!in_lds) __builtin_amdgcn_s_waitcnt(0);
+    }
   }
   __syncthreads();
+  if (in_lds) for (uint32_t i = lane; i < n; i += PANN_WAVE) K[i] = Ks[i];     // the tail counter reads the kill flags
   if (A.rows_out) {
     for (uint32_t j = lane; j < A.rows_stride; j += PANN_WAVE)
       A.rows_out[(size_t)oi * A.rows_stride + j] = j < nsel ? Out[j] : SENTINEL;
@@ -388,11 +503,10 @@ static size_t scan_temp_bytes(uint32_t size) {
   return t;
 }
 
-static size_t query_lds_bytes(const DeviceIndex& ix) { return ix.nch == 1 ? 0 : (size_t)ix.nch * ix.lpc * 16; }
 
 // keys -> segmented sort -> greedy.  keys_a holds the unsorted keys, keys_b receives the sorted ones.
 static int run_prune(const DeviceIndex& ix, PruneArgs pa, GreedyArgs ga, uint64_t* keys_a, uint64_t* keys_b,
-                     uint32_t total_keys, void* sort_tmp, size_t sort_tmp_bytes, hipStream_t st) {
+                     uint32_t total_keys, void* sort_tmp, size_t sort_tmp_bytes, hipStream_t st, uint32_t max_seg_len) {
   const uint32_t m = pa.m;
   if (m == 0) return PANN_OK;
   const size_t qb = query_lds_bytes(ix);
@@ -404,7 +518,10 @@ static int run_prune(const DeviceIndex& ix, PruneArgs pa, GreedyArgs ga, uint64_
   PANN_HIP(rocprim::segmented_radix_sort_keys(sort_tmp, sort_tmp_bytes, keys_a, keys_b, total_keys, m,
                                               (const uint32_t*)pa.seg_begin, (const uint32_t*)pa.seg_end, 0, 64, st));
   ga.keys = keys_b; ga.seg_begin = pa.seg_begin; ga.seg_end = pa.seg_end;
-#define CALL_GREEDY(DT, MT, L, N1) hipLaunchKernelGGL((prune_greedy_kernel<DT, MT, L, N1>), dim3(m), dim3(PANN_WAVE), qb, st, ga)
+  { static const char* sp = getenv("PANN_PRUNE_SINGLE"); ga.single_pick = sp ? (uint32_t)atoi(sp) : 0u; }   // A/B switch: 1 one pick per pass, 2 lists in HBM
+  ga.kcap = std::min<uint32_t>((max_seg_len + 63) / 64 * 64, 3072);                       // <= 24 KB of keys per wave
+  const size_t gb_lds = qb * 4 + (size_t)((ga.R + 3) & ~3u) * 4 + (size_t)ga.kcap * 8;      // 4 = PB query slots
+#define CALL_GREEDY(DT, MT, L, N1) hipLaunchKernelGGL((prune_greedy_kernel<DT, MT, L, N1>), dim3(m), dim3(PANN_WAVE), gb_lds, st, ga)
   PANN_TYPE_SWITCH(ix, CALL_GREEDY);
 #undef CALL_GREEDY
   PANN_HIP(hipGetLastError());
@@ -424,12 +541,13 @@ int robust_prune_batch_host(const DeviceIndex& ix, Workspace& ws, hipStream_t st
   if (R == 0 || R > 1024) { set_error("pann_robust_prune_batch: R out of range [1,1024]"); return PANN_ERR_BAD_ARG; }
   const uint64_t ncand = cand_offsets[m];
   std::vector<uint64_t> h_base(m); std::vector<uint32_t> h_cnt(m), h_seg(m);
-  uint64_t total = 0;
+  uint64_t total = 0, max_seg = 0;
   for (uint64_t i = 0; i < m; i++) {
     if (owners[i] >= ix.n) { set_error("pann_robust_prune_batch: owner out of range"); return PANN_ERR_BAD_ARG; }
     h_base[i] = cand_offsets[i]; h_cnt[i] = (uint32_t)(cand_offsets[i + 1] - cand_offsets[i]);
     h_seg[i] = (uint32_t)total;
     total += h_cnt[i] + (add_out_nbrs ? ix.gstride : 0);
+    max_seg = std::max<uint64_t>(max_seg, h_cnt[i] + (add_out_nbrs ? ix.gstride : 0));
   }
   for (uint64_t j = 0; j < ncand; j++)
     if (cand_ids[j] >= ix.n) { set_error("pann_robust_prune_batch: candidate id out of range"); return PANN_ERR_BAD_ARG; }
@@ -467,7 +585,7 @@ int robust_prune_batch_host(const DeviceIndex& ix, Workspace& ws, hipStream_t st
   ga.pv = pa.pv; ga.dbytes = ix.dbytes; ga.owners = d_own; ga.alpha = alpha; ga.R = R;
   ga.rows_out = d_rows; ga.rows_stride = R; ga.cnt_out = d_rcnt; ga.graph = nullptr; ga.gstride = ix.gstride;
   ga.dcmps = d_dc; ga.m = (uint32_t)m;
-  if (int rc = run_prune(ix, pa, ga, ka, kb, (uint32_t)total, d_tmp, stmp, st)) return rc;
+  if (int rc = run_prune(ix, pa, ga, ka, kb, (uint32_t)total, d_tmp, stmp, st, (uint32_t)std::min<uint64_t>(max_seg, 1u << 30))) return rc;
   std::vector<uint32_t> h_rows(m * R), h_rcnt(m);
   PANN_HIP(hipMemcpyAsync(h_rows.data(), d_rows, m * R * 4, hipMemcpyDeviceToHost, st));
   PANN_HIP(hipMemcpyAsync(h_rcnt.data(), d_rcnt, m * 4, hipMemcpyDeviceToHost, st));
@@ -551,7 +669,7 @@ int insert_batch_dev(const DeviceIndex& ix, Workspace& ws, Workspace& ws2, Works
     ga.pv = pa.pv; ga.dbytes = ix.dbytes; ga.owners = d_batch; ga.alpha = alpha; ga.R = R;
     ga.rows_out = d_rows; ga.rows_stride = R; ga.cnt_out = d_rcnt; ga.graph = nullptr; ga.gstride = ix.gstride;
     ga.dcmps = d_dc; ga.m = m;
-    if (int rc = run_prune(ix, pa, ga, ka, kb, (uint32_t)total_keys, d_tmp, stmp, st)) return rc;
+    if (int rc = run_prune(ix, pa, ga, ka, kb, (uint32_t)total_keys, d_tmp, stmp, st, seg_stride)) return rc;
     // ---- :268-270 write the new out-neighbourhoods (only now: searches and prunes saw the old graph)
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(m), dim3(PANN_WAVE), 0, st, ix.graph, ix.gstride, d_batch, d_rows, R, m);
     PANN_HIP(hipGetLastError());
@@ -594,7 +712,8 @@ int insert_batch_dev(const DeviceIndex& ix, Workspace& ws, Workspace& ws2, Works
       std::vector<uint32_t> h_len(nheavy), h_seg(nheavy);
       PANN_HIP(hipMemcpy(h_len.data(), d_hlen, (size_t)nheavy * 4, hipMemcpyDeviceToHost));
       uint64_t tk = 0;
-      for (uint32_t i = 0; i < nheavy; i++) { h_seg[i] = (uint32_t)tk; tk += h_len[i]; }
+      uint32_t max_len = 0;
+      for (uint32_t i = 0; i < nheavy; i++) { h_seg[i] = (uint32_t)tk; tk += h_len[i]; max_len = std::max(max_len, h_len[i]); }
       if (tk >= 0xFFFFFFF0ull) { set_error("vamana insert: re-prune too large"); return PANN_ERR_BAD_ARG; }
       const size_t stmp2 = seg_sort_temp_bytes((uint32_t)tk, nheavy);
       uint32_t *h_dseg, *h_dsend, *h_ddc; uint64_t *hk_a, *hk_b; void* h_tmp;
@@ -615,7 +734,7 @@ int insert_batch_dev(const DeviceIndex& ix, Workspace& ws, Workspace& ws2, Works
       gb.pv = pa.pv; gb.dbytes = ix.dbytes; gb.owners = d_hown; gb.alpha = alpha; gb.R = R;
       gb.rows_out = nullptr; gb.rows_stride = 0; gb.cnt_out = nullptr; gb.graph = ix.graph; gb.gstride = ix.gstride;
       gb.dcmps = h_ddc; gb.m = nheavy;
-      if (int rc = run_prune(ix, pb, gb, hk_a, hk_b, (uint32_t)tk, h_tmp, stmp2, st)) return rc;
+      if (int rc = run_prune(ix, pb, gb, hk_a, hk_b, (uint32_t)tk, h_tmp, stmp2, st, max_len)) return rc;
       if (stats) {
         std::vector<uint32_t> hd(nheavy);
         PANN_HIP(hipMemcpyAsync(hd.data(), h_ddc, (size_t)nheavy * 4, hipMemcpyDeviceToHost, st));

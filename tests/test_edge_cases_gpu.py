@@ -139,3 +139,49 @@ def test_zero_dimension_padding_and_odd_dims(oracle):
         g = ix.batch_search(Q, k=5, beam=16, out_k=16)
         _cmp(o, g)
         ix.close()
+
+
+_REPLAY_IDS = [13684, 70653, 68340, 65698, 24635, 61076, 64589, 14896, 6023, 7202, 63156, 4421, 101363, 91014, 104600, 58243, 94466, 14090, 45263, 106329, 10443, 81886, 54875, 99683, 60743, 31593, 26379, 85117, 15397, 53897, 30931, 43329, 45736, 93829, 79979, 104814, 98773, 70120, 84091, 99167, 65109, 61660, 8861, 58549, 3391, 20439, 81582, 41645, 6255, 71749, 96325, 89412, 47683, 77135, 85256, 49658, 26603, 90426]
+
+
+def test_rows_of_64_bytes_use_the_lds_query_variants(oracle):
+    """d*esize <= 64 -> layout lpc 4 / nch 1, which runs the GENERIC kernel variants (query in LDS) although the row
+    is a single chunk per lane.  The host once sized the dynamic LDS for the register variants in this case
+    (64 bytes short): found through one re-prune whose distance_comps differed (the list below, owner 100748
+    of a 110K-point build).  Every kernel family is exercised on 64-byte rows here."""
+    n = 110_000
+    X = datasets.sift_like(n, 32, seed=1234, dtype=np.uint8)
+    G0 = np.zeros((n, 17), np.uint32)
+    ix = DeviceIndex(X, G0)
+    ids = np.array(_REPLAY_IDS, np.uint32)
+    owners = np.array([100748], np.uint32); off = np.array([0, len(ids)], np.uint64)
+    for R in (16, 58):
+        ro, dco = oracle.robust_prune_batch(X, G0, owners, ids, None, off, 1.2, R, add=False)
+        rg, dcg = ix.robust_prune_batch(owners, ids, off, 1.2, R, add_out_nbrs=False)
+        np.testing.assert_array_equal(ro, rg); np.testing.assert_array_equal(dco, dcg)
+    ix.close()
+    for dtype, d in ((np.uint8, 48), (np.float32, 16), (np.float16, 32)):
+        m = 5000
+        Y = datasets.sift_like(m, d, seed=5, dtype=dtype); Q = datasets.sift_like(200, d, seed=6, dtype=dtype)
+        G, _ = oracle.vamana_build(Y, 24, 48, 1.2, seed=3)
+        iy = DeviceIndex(Y, G)
+        for beam in (20, 64, 100, 200):
+            o = oracle.batch_search(Y, G, queries=Q, k=10, beam=beam)
+            g = iy.batch_search(Q, k=10, beam=beam)
+            for f in ("ids", "visited_count", "dist_cmps"):
+                np.testing.assert_array_equal(o[f], g[f], err_msg=f"{np.dtype(dtype).name} d={d} beam={beam} {f}")
+        sel = np.arange(0, 700, dtype=np.uint32)
+        oi, od = oracle.leaf_knn(Y, sel, 10)
+        gi, gd = iy.leaf_knn(sel, 10)
+        np.testing.assert_array_equal(oi, gi); np.testing.assert_array_equal(od, gd)
+        st = iy.batch_search(Q, k=5, beam=16)["ids"]
+        r2 = float(np.median(oracle.bruteforce_knn(Y, Q, 20)[1][:, -1]))
+        o = oracle.range_search(Y, G, st, r2, 256, queries=Q); g = iy.range_search(st, r2, 256, queries=Q)
+        np.testing.assert_array_equal(o["ids"], g["ids"]); np.testing.assert_array_equal(o["dist_cmps"], g["dist_cmps"])
+        iy.close()
+        iz = DeviceIndex(Y, max_degree=24)
+        iz.vamana_build(24, 48, 1.2, seed=3)
+        Gd = iz.get_graph()
+        cols = np.arange(24)[None, :]
+        np.testing.assert_array_equal(np.where(cols < G[:, :1], G[:, 1:], 0), np.where(cols < Gd[:, :1], Gd[:, 1:], 0))
+        iz.close()
