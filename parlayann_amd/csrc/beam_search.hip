@@ -59,6 +59,13 @@ namespace pann {
 #define PANN_STAMP(slot) do { } while (0)
 #endif
 
+// every kernel of this file runs ONE wavefront per workgroup
+#ifdef PANN_FULL_BARRIERS
+#define PANN_WSYNC() __syncthreads()
+#else
+#define PANN_WSYNC() wave_lds_sync()
+#endif
+
 struct BSParams {
   const uint8_t* points; uint32_t pstride; uint32_t dbytes; uint32_t nch; uint32_t exact;
   const uint32_t* graph; uint32_t gstride; uint32_t max_deg;
@@ -92,7 +99,7 @@ __device__ __forceinline__ void hstore(uint32_t* H, uint32_t s, uint32_t v) {
 template <bool HASH_LDS>
 __device__ __forceinline__ void hsync() {
   if constexpr (!HASH_LDS) __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): global table ops retire in order
-  __syncthreads();
+  PANN_WSYNC();
 }
 
 // first index in sorted A[0..n) with A[i] >= key
@@ -130,9 +137,9 @@ __device__ __forceinline__ bool filter_update(uint32_t* H, uint32_t hmask, bool 
   uint32_t* Hp = reinterpret_cast<uint32_t*>(T + 1024);                 // LDS part of a split table
   if constexpr (HASH_LDS) {
     old = active ? H[s] : 0u;
-    __syncthreads();
+    PANN_WSYNC();
     if (active) H[s] = (uint32_t)lane;                   // some lane of each slot group wins
-    __syncthreads();
+    PANN_WSYNC();
     w = active ? H[s] : (uint32_t)lane;
   } else {
     __builtin_amdgcn_s_waitcnt(0);                       // the previous call's table stores have been acknowledged
@@ -140,7 +147,7 @@ __device__ __forceinline__ bool filter_update(uint32_t* H, uint32_t hmask, bool 
     if (active) old = in_hbm ? __hip_atomic_load(H + (s >> hb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : Hp[split_lds_index(s, hb)];
     const uint32_t t = s & 1023u;
     if (active) T[t] = (uint8_t)lane;
-    __syncthreads();
+    PANN_WSYNC();
     w = active ? (uint32_t)T[t] : (uint32_t)lane;
   }
   uint64_t losers = __ballot(active && w != (uint32_t)lane);
@@ -160,15 +167,15 @@ __device__ __forceinline__ bool filter_update(uint32_t* H, uint32_t hmask, bool 
   const uint32_t a_prev = __shfl(a, prev < 0 ? lane : prev);
   const bool seen = active && (prev >= 0 ? (a_prev == a) : (old == a));
   if constexpr (HASH_LDS) {
-    __syncthreads();
+    PANN_WSYNC();
     if (active && last) H[s] = a;
-    __syncthreads();
+    PANN_WSYNC();
   } else {
     if (active && last) {
       if (in_hbm) __hip_atomic_store(H + (s >> hb), a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else Hp[split_lds_index(s, hb)] = a;
     }
-    __syncthreads();                                     // T (and the LDS part) may be touched by the next call
+    PANN_WSYNC();                                     // T (and the LDS part) may be touched by the next call
   }
   return seen;
 }
@@ -251,11 +258,11 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES) beam_search_kernel(B
       const uint32_t a = act ? P.starts[(size_t)qi * P.starts_stride + i] : 0u;
       (void)filter_update<HASH_LDS>(H, hmask, act, a, lane, reinterpret_cast<uint8_t*>(Hl));
       if (act) PANN_PL[lane] = a;
-      __syncthreads();
+      PANN_WSYNC();
       const uint32_t m = min(P.nstarts - s0, (uint32_t)PANN_WAVE);
       // every start enters the frontier: cutoff above any finite distance
       c = gather_distances<DT, METRIC, LPC, NCH1, 4>(P, qreg, qlds, PANN_PL, m, 0xFFFFFFFFu, C, c, lane);
-      __syncthreads();
+      PANN_WSYNC();
     }
 
     bool first = true;  // the start-point pseudo-merge: no cut-prune, no visit
@@ -310,14 +317,14 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES) beam_search_kernel(B
           const uint32_t m = __popcll(km);
           if (keep) PANN_PL[lanes_below(km, lane)] = a;
           dcmps += m;                                                 // :137,155
-          __syncthreads();
+          PANN_WSYNC();
           PANN_STAMP(2);   // filter + compaction
           if (m) c = gather_distances<DT, METRIC, LPC, NCH1, PANN_GU>(P, qreg, qlds, PANN_PL, m, cutoff_ord, C, c, lane);
-          __syncthreads();
+          PANN_WSYNC();
           PANN_STAMP(3);   // gather + distances
         }
         // ---- skip the merge while too few candidates (:162-168) ----
-        __syncthreads();
+        PANN_WSYNC();
         const bool skip = (c == 0) || (P.skip_enabled && c < beam / 8 && more_unvisited);
         do_merge = !skip;
       }
@@ -337,11 +344,11 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES) beam_search_kernel(B
               dead |= (p < f && F[p] == key);
               if (dead) key = KEY_INF;
             }
-            __syncthreads();       // all reads of C[0..j) by this chunk are done
+            PANN_WSYNC();       // all reads of C[0..j) by this chunk are done
             if (j < c) { C[j] = key; CP[j] = (uint16_t)p; }
             // later chunks compare against earlier ORIGINAL keys; a killed earlier key was itself a
             // duplicate of a still earlier live one (or of F), so the verdict is unchanged.
-            __syncthreads();
+            PANN_WSYNC();
           }
           // A2: rank among live candidates -> direct placement into NF
           uint32_t nvalid = 0;
@@ -372,7 +379,7 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES) beam_search_kernel(B
               if (pos < beam) { NF[pos] = key; NFv[pos] = Fv[e]; }
             }
           }
-          __syncthreads();
+          PANN_WSYNC();
           const uint32_t f_old = f;
           uint32_t f_new = min(f_old + nvalid, beam);   // :185
           // ---- cut-prune (:190-195) ----
@@ -416,7 +423,7 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES) beam_search_kernel(B
           { uint64_t* t = F; F = NF; NF = t; uint8_t* tv = Fv; Fv = NFv; NFv = tv; }
           f = f_new;
           c = 0;                      // candidates.clear() (:182)
-          __syncthreads();
+          PANN_WSYNC();
         }
       }
       PANN_STAMP(4);     // merge (or nothing when skipped)
@@ -441,7 +448,7 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES) beam_search_kernel(B
       if (P.out.dist_cmps) P.out.dist_cmps[qi] = dcmps;
       if (P.out.degree_sum) P.out.degree_sum[qi] = degsum;
     }
-    __syncthreads();
+    PANN_WSYNC();
     if constexpr (HASH_LDS) break;
     else {
       qi = 0;
@@ -479,7 +486,7 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES_B64) beam_search_b64_
   const uint8_t* qrow = P.query_ids ? P.points + (uint64_t)self * P.pstride : P.queries + (uint64_t)qi * P.qstride;
   QReg<DT> qreg{};
   load_query<DT, LPC, NCH1>(qrow, P.dbytes, P.nch, qreg, qlds, lane);
-  __syncthreads();
+  PANN_WSYNC();
 
   uint32_t f = 0, c = 0, nvis = 0, dcmps = P.nstarts, degsum = 0, ndrop = 0;
   uint64_t fkey = KEY_INF;
@@ -496,9 +503,9 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES_B64) beam_search_b64_
     const uint32_t a = act ? P.starts[(size_t)qi * P.starts_stride + lane] : 0u;
     (void)filter_update<true>(H, hmask, act, a, lane);
     if (act) Pl[lane] = a;
-    __syncthreads();
+    PANN_WSYNC();
     c = gather_distances<DT, METRIC, LPC, NCH1, 4>(P, qreg, qlds, Pl, P.nstarts, 0xFFFFFFFFu, C, c, lane);
-    __syncthreads();
+    PANN_WSYNC();
   }
 
   bool first = true;
@@ -542,10 +549,10 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES_B64) beam_search_b64_
         const uint32_t m = __popcll(km);
         if (keep) Pl[lanes_below(km, lane)] = a;
         dcmps += m;
-        __syncthreads();
+        PANN_WSYNC();
         PANN_STAMP(2);
         if (m) c = gather_distances<DT, METRIC, LPC, NCH1, PANN_GU>(P, qreg, qlds, Pl, m, cutoff_ord, C, c, lane);
-        __syncthreads();
+        PANN_WSYNC();
         PANN_STAMP(3);
       }
       const bool skip = (c == 0) || (P.skip_enabled && c < beam / 8 && more_unvisited);   // :162-168
@@ -592,11 +599,11 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES_B64) beam_search_b64_
           }
           lt += __popcll(lm);
         }
-        __syncthreads();
+        PANN_WSYNC();
         f = min(f + nvalid, beam);
         fkey = (lane < (int)f) ? S[lane] : KEY_INF;
         fflag = (lane < (int)f) ? (uint32_t)Sv[lane] : 0u;
-        __syncthreads();
+        PANN_WSYNC();
       }
       uint32_t f_new = f;
       if (!first && P.cut_enabled && f_new > P.k) {              // cut-prune (:190-195)
@@ -701,11 +708,14 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
     const uint32_t a = act ? P.starts[(size_t)qi * P.starts_stride + lane] : 0u;
     (void)filter_update<HASH_LDS>(H, hmask, act, a, lane, T, hb);
     if (act) Pl[lane] = a;
-    __syncthreads();
+    PANN_WSYNC();
     c = gather_distances<DT, METRIC, LPC, NCH1, 4>(P, qreg, qlds, Pl, P.nstarts, 0xFFFFFFFFu, C, c, lane);
-    __syncthreads();
+    PANN_WSYNC();
   }
 
+  // Speculative adjacency-row fetch: while the candidates of vertex v are gathered, the row of the frontier's NEXT
+  // unvisited entry is already requested; it is the next vertex unless the merge puts something in front of it.
+  uint32_t pref_id = SENTINEL, pref_row = SENTINEL;
   bool first = true;
   for (;;) {
     bool do_merge = first;
@@ -732,10 +742,23 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
       if (f == beam) cutoff_ord = (uint32_t)(entry_key(f - 1) >> 32);
 
       const uint32_t* row = P.graph + (size_t)cur * P.gstride;
+      const bool pref_hit = (pref_id == cur);
+      const uint32_t pref_val = pref_row;
+      uint32_t next_id = SENTINEL;   // the entry after `cur` among the unvisited ones
+      {
+        uint64_t r0 = um0, r1 = um1;
+        if (r0) r0 &= r0 - 1; else r1 &= r1 - 1;
+        if (r0 | r1) {
+          const int nx = r0 ? __ffsll((unsigned long long)r0) - 1 : 64 + __ffsll((unsigned long long)r1) - 1;
+          next_id = key_id(entry_key((uint32_t)nx));
+        }
+      }
+      pref_id = SENTINEL;
       for (uint32_t i0 = 0; i0 < P.gstride; i0 += PANN_WAVE) {
         const uint32_t i = i0 + lane;
         uint32_t a = SENTINEL;
-        if (i < P.gstride) a = row[i];
+        if (i0 == 0 && pref_hit) a = pref_val;
+        else if (i < P.gstride) a = row[i];
         const bool act = (a != SENTINEL) && (i < P.degree_limit);
         const uint64_t am = __ballot(act);
         PANN_STAMP(1);
@@ -747,10 +770,16 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
         const uint32_t m = __popcll(km);
         if (keep) Pl[lanes_below(km, lane)] = a;
         dcmps += m;
-        __syncthreads();
+        PANN_WSYNC();
         PANN_STAMP(2);
+        // requested after the filter's table loads, right before the gather's.  Only for base-point queries (the
+        // builder's searches: f32 d=96 search phase -5.5 %); external beam-128 queries measured 2 % slower with it.
+        if (i0 == 0 && next_id != SENTINEL && P.query_ids) {
+          pref_id = next_id;
+          pref_row = (lane < (int)P.gstride) ? P.graph[(size_t)next_id * P.gstride + lane] : SENTINEL;
+        }
         if (m) c = gather_distances<DT, METRIC, LPC, NCH1, PANN_GU_B128(LPC)>(P, qreg, qlds, Pl, m, cutoff_ord, C, c, lane);
-        __syncthreads();
+        PANN_WSYNC();
         PANN_STAMP(3);
       }
       const bool skip = (c == 0) || (P.skip_enabled && c < beam / 8 && more_unvisited);
@@ -802,7 +831,7 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
             lt += __popcll(lm);
           }
         }
-        __syncthreads();
+        PANN_WSYNC();
         f = min(f + nvalid, beam);
 #pragma unroll
         for (int r = 0; r < RB; r++) {
@@ -810,7 +839,7 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
           fkey[r] = in ? S[lane + 64 * r] : KEY_INF;
           fflag[r] = in ? (uint32_t)Sv[lane + 64 * r] : 0u;
         }
-        __syncthreads();
+        PANN_WSYNC();
       }
       uint32_t f_new = f;
       if (!first && P.cut_enabled && f_new > P.k) {
@@ -869,7 +898,7 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
   if constexpr (HASH_LDS) {
     break;
   } else {
-    __syncthreads();
+    PANN_WSYNC();
     if (lane == 0) qi = atomicAdd(P.work_counter, 1u);
     qi = __builtin_amdgcn_readfirstlane(qi);
   }

@@ -44,10 +44,6 @@ struct DenseArgs {
   const uint32_t* tile_a0;    // [grid.x] first A row (global index) of each tile
 };
 
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
 
 // sorted insert of key x into list[0..mcap) (ascending, KEY_INF padded), dropping the last entry
 __device__ __forceinline__ void list_insert(uint64_t* list, uint32_t mcap, uint64_t x, int lane) {

@@ -443,6 +443,15 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
   return ((uint64_t)hi << 32) | lo;
 }
 
+// Block-wide sync for kernels whose workgroup is ONE wavefront: LDS instructions of a wave execute in order, so all
+// that is needed between a lane's ds_write and another lane's ds_read is that the compiler keeps the order.
+// Unlike __syncthreads() this does not drain outstanding global loads / stores (s_waitcnt vmcnt(0)), so memory
+// requests stay in flight across the phases of an iteration.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ uint32_t lanes_below(uint64_t m, int lane) {
   return __popcll(m & ((1ull << lane) - 1ull));
 }
