@@ -35,9 +35,10 @@ namespace pann {
 #define PANN_GU 4   /* candidate groups in flight per lane in the main gather */
 #endif
 #ifndef PANN_GU_B128
-/* beam 65..128: the 16 KB filter limits a CU to 8 queries; a whole adjacency row per memory round trip
-   (16 groups in flight) was measured SLOWER than 4 (C3 build search phase 1.50 s vs 1.19 s) */
-#define PANN_GU_B128(LPC) 4
+/* beam 65..128: a whole adjacency row per memory round trip (16 groups in flight) was measured SLOWER than 4
+   (C3 build search phase 1.50 s vs 1.19 s); rows of several chunks per lane halve the group count inside
+   gather_tile, so they ask for 8 here (= 4 groups x 3 chunks in flight) */
+#define PANN_GU_B128(LPC, NCH1) ((NCH1) ? 4 : 8)
 #endif
 #ifndef PANN_MINWAVES
 #define PANN_MINWAVES 1
@@ -778,7 +779,7 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
           pref_id = next_id;
           pref_row = (lane < (int)P.gstride) ? P.graph[(size_t)next_id * P.gstride + lane] : SENTINEL;
         }
-        if (m) c = gather_distances<DT, METRIC, LPC, NCH1, PANN_GU_B128(LPC)>(P, qreg, qlds, Pl, m, cutoff_ord, C, c, lane);
+        if (m) c = gather_distances<DT, METRIC, LPC, NCH1, PANN_GU_B128(LPC, NCH1)>(P, qreg, qlds, Pl, m, cutoff_ord, C, c, lane);
         PANN_WSYNC();
         PANN_STAMP(3);
       }
