@@ -10,7 +10,7 @@ nq = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
 grid = f"grid={nq * 64}"
 s = open("gpurun_out/summary_stats.txt").read().splitlines()
 out = [f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --no-cpu-baseline   (MI355X, {tag})",
-       "# whole process: includes the 1M-point Vamana build (its searches use the generic beam_search_kernel, L=128) and the brute-force ground truth"]
+       "# whole process: includes the 1M-point Vamana build (its searches run beam_search_b128_kernel, L=128) and the brute-force ground truth"]
 out += [l[:200] for l in s[:16] if not l.startswith("columns")]
 out += ["", f"# dispatches grouped by grid size; {grid} ({nq} waves x 64) are the TIMED query steps (3 warmup + 20)"]
 out += [l for l in s if grid in l]
