@@ -54,3 +54,43 @@ def test_device_reproduces_golden(gold):
     np.testing.assert_array_equal(G[:, 0], G2[:, 0])
     np.testing.assert_array_equal(np.where(cols < G[:, :1], G[:, 1:], 0), G2[:, 1:])
     ix.close(); ix2.close()
+
+
+G2_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_v2.npz")
+
+
+def test_oracle_reproduces_golden_v2(oracle):
+    """range search, HCNNG, quantisers, real-valued float search: the oracle regenerates tests/golden/oracle_v2.npz"""
+    from golden.make_golden_v2 import compute
+    gold = np.load(G2_PATH)
+    now = compute(oracle)
+    assert set(now) == set(gold.files)
+    for k in gold.files:
+        np.testing.assert_array_equal(gold[k], now[k], err_msg=k)
+
+
+@pytest.mark.gpu
+def test_device_reproduces_golden_v2():
+    from parlayann_amd import DeviceIndex, quantize
+    gold = np.load(G2_PATH)
+    ix = DeviceIndex(gold["rs_X"], gold["rs_G"])
+    r = ix.range_search(gold["rs_starts"], float(gold["rs_r2"]), 128, queries=gold["rs_Q"])
+    np.testing.assert_array_equal(r["ids"], gold["rs_ids"]); np.testing.assert_array_equal(r["counts"], gold["rs_counts"])
+    np.testing.assert_array_equal(r["dist_cmps"], gold["rs_cmps"])
+    ix.close()
+    ih = DeviceIndex(gold["rs_X"], max_degree=gold["hc_G"].shape[1] - 1)
+    ih.hcnng_build(3, 100, 3, seed=9)
+    np.testing.assert_array_equal(ih.get_graph(), gold["hc_G"])
+    ih.close()
+    p = quantize.euclid_u8_params(gold["qz_F"])
+    assert p.slope == gold["qz_slope"] and int(p.offset) == int(gold["qz_off"])
+    np.testing.assert_array_equal(quantize.euclid_u8_translate(gold["qz_F"], p), gold["qz_u8"])
+    for trim in (0, 1):
+        mv = quantize.mips_i8_max_val(gold["qz_M"], trim=bool(trim))
+        assert np.float32(mv) == gold[f"qz_mv{trim}"]
+        np.testing.assert_array_equal(quantize.mips_i8_translate(gold["qz_M"], mv), gold[f"qz_i8_{trim}"])
+    fx = DeviceIndex(gold["fl_X"], gold["fl_G"], exact_float_order=True)          # real-valued floats: exact-order mode
+    fr = fx.batch_search(gold["fl_Q"], k=10, beam=32, out_k=16)
+    np.testing.assert_array_equal(fr["ids"], gold["fl_ids"]); np.testing.assert_array_equal(fr["dists"].view(np.uint32), gold["fl_dists"].view(np.uint32))
+    np.testing.assert_array_equal(fr["dist_cmps"], gold["fl_cmps"]); np.testing.assert_array_equal(fr["visited_count"], gold["fl_vis"])
+    fx.close()
