@@ -155,15 +155,16 @@ __global__ void __launch_bounds__(PANN_WAVE) prune_greedy_kernel(GreedyArgs A) {
   // together and every live candidate vector is fetched once and scored against all of them; the sequential
   // semantics (a pick killed by an earlier pick of the same pass is not a pick; a candidate is counted for and
   // killed by the selected picks in order) are then resolved from those distances -- a quarter of the dependent
-  // memory round trips of one-pick-at-a-time.  Lists in HBM and the exact-float-order mode keep the plain loop.
+  // memory round trips of one-pick-at-a-time.  (Lists longer than kcap are walked in HBM with the same logic; the
+  // exact-float-order mode keeps the plain loop.)
   constexpr int PB = 4;
   __shared__ float Dd[PB][PANN_WAVE];
   const uint32_t qstride4 = NCH1 ? 0u : A.pv.nch * LPC;
-  if (in_lds && !A.pv.exact && !(A.single_pick & 1u)) {
+  if (!A.pv.exact && !(A.single_pick & 1u)) {
     uint32_t idx = 0;
     while (idx < n && nsel < A.R) {
       const uint32_t wi = idx + lane;
-      const uint32_t idw = wi < n ? key_id(Ks[wi]) : SENTINEL;
+      const uint32_t idw = wi < n ? key_id(ldk(wi)) : SENTINEL;
       uint64_t pm = __ballot(idw != SENTINEL && idw != p);                 // :99
       if (pm == 0ull) { idx += PANN_WAVE; continue; }
       uint32_t ppos[PB], pid[PB];
@@ -191,7 +192,7 @@ __global__ void __launch_bounds__(PANN_WAVE) prune_greedy_kernel(GreedyArgs A) {
       const uint32_t nsel0 = nsel;
       for (uint32_t t0 = ppos[0] + 1; t0 < n; t0 += PANN_WAVE) {             // :105-115
         const uint32_t i = t0 + lane;
-        const uint64_t k = i < n ? Ks[i] : KEY_INF;
+        const uint64_t k = i < n ? ldk(i) : KEY_INF;
         const bool live = (i < n) && (key_id(k) != SENTINEL);
         const uint64_t lm = __ballot(live);
         const uint32_t mm = __popcll(lm);
@@ -242,7 +243,7 @@ __global__ void __launch_bounds__(PANN_WAVE) prune_greedy_kernel(GreedyArgs A) {
             if (elig && A.alpha * (double)dl[j] <= (double)dpp) alive = false;
           }
         }
-        if (me && !alive) Ks[mypos] = ((uint64_t)f2ord(dpp) << 32) | SENTINEL;   // candidates[i].first = -1
+        if (me && !alive) stk(mypos, ((uint64_t)f2ord(dpp) << 32) | SENTINEL);   // candidates[i].first = -1
         __syncthreads();
       }
       if (first_tile) { sel[0] = true; nsel++; }                             // nothing live after the pick
@@ -252,6 +253,7 @@ __global__ void __launch_bounds__(PANN_WAVE) prune_greedy_kernel(GreedyArgs A) {
         for (int j = 0; j < PB; j++) if (sel[j]) Out[at++] = pid[j];         // :103
       }
       idx = ppos[nb - 1] + 1;
+      if (!in_lds) __builtin_amdgcn_s_waitcnt(0);                              // kill flags of this pass have landed
     }
   } else {
     for (uint32_t idx = 0; idx < n && nsel < A.R; idx++) {
