@@ -1,0 +1,126 @@
+"""BASELINE config[1] at FULL size (1M x 128 fp16, Vamana R=64 L=128 x2 built on the device, 10K queries, beam 64):
+size-independent properties of the hot path -- well-formed graph, sorted / duplicate-free / exact results,
+determinism, permutation invariance, recall against exact ground truth -- plus a bit-exact oracle check of a
+sample of the queries on the full graph (the oracle finishes 300 queries on a 1M-point graph in seconds)."""
+import numpy as np
+import pytest
+
+from parlayann_amd import DeviceIndex, datasets
+from parlayann_amd.recall import recall_at_k
+
+pytestmark = pytest.mark.gpu
+N, D, NQ, R, L = 1_000_000, 128, 10_000, 64, 128
+
+
+@pytest.fixture(scope="module")
+def built():
+    X = datasets.sift1m_like(N, D, seed=1234, dtype=np.float16)
+    Q = datasets.sift1m_like(NQ, D, seed=4321, dtype=np.float16)
+    ix = DeviceIndex(X, max_degree=R)
+    st = ix.vamana_build(R, L, 1.15, num_passes=2, seed=1)
+    yield X, Q, ix, st
+    ix.close()
+
+
+def test_graph_is_well_formed_and_deterministic(built):
+    X, Q, ix, st = built
+    G = ix.get_graph()
+    deg = G[:, 0]
+    assert deg.max() <= R and deg.min() >= 1
+    cols = np.arange(R)[None, :]
+    valid = cols < deg[:, None]
+    nb = G[:, 1:]
+    assert int(nb[valid].max()) < N
+    assert not (nb == np.arange(N, dtype=np.uint32)[:, None])[valid].any()            # no self loops
+    srt = np.sort(np.where(valid, nb, np.uint32(0xFFFFFFFF)), axis=1)
+    assert not ((srt[:, 1:] == srt[:, :-1]) & (srt[:, 1:] != 0xFFFFFFFF)).any()       # no repeated neighbour in a row
+    # rows are sorted by (distance to the owner, id) (final neighbour sort, vamana/index.h:180-185): sample of rows
+    rows = np.random.default_rng(0).choice(N, 2000, replace=False)
+    a = np.repeat(rows, R).astype(np.uint32); b = nb[rows].reshape(-1).copy()
+    m = valid[rows].reshape(-1)
+    b[~m] = a[~m]
+    d = ix.pair_distances(a, b).reshape(len(rows), R)
+    for i in range(len(rows)):
+        k = deg[rows[i]]
+        key = list(zip(d[i, :k].tolist(), nb[rows[i], :k].tolist()))
+        assert key == sorted(key)
+    # a second build with the same seed gives the same graph
+    ix2 = DeviceIndex(X, max_degree=R)
+    st2 = ix2.vamana_build(R, L, 1.15, num_passes=2, seed=1)
+    G2 = ix2.get_graph()
+    ix2.close()
+    np.testing.assert_array_equal(deg, G2[:, 0])
+    np.testing.assert_array_equal(np.where(valid, nb, 0), np.where(valid, G2[:, 1:], 0))
+    assert (st.search_dist_cmps, st.prune_dist_cmps) == (st2.search_dist_cmps, st2.prune_dist_cmps)
+
+
+def test_search_results_are_sorted_exact_and_reproducible(built, oracle):
+    X, Q, ix, _ = built
+    r = ix.batch_search(Q, k=10, beam=64)
+    ids, dists = r["ids"], r["dists"]
+    assert ids.shape == (NQ, 10) and int(ids.max()) < N
+    s = np.sort(ids, axis=1)
+    assert not (s[:, 1:] == s[:, :-1]).any()                                          # no id twice
+    assert (np.diff(dists, axis=1) >= 0).all()                                         # ascending distance ...
+    ties = np.diff(dists, axis=1) == 0
+    assert (np.diff(ids.astype(np.int64), axis=1)[ties] > 0).all()                    # ... ties by ascending id
+    # the reported distances are the true distances (integer-valued data: exact in any order)
+    sel = np.random.default_rng(1).choice(NQ, 64, replace=False)
+    for qi in sel:
+        want = ix.query_distances(Q[qi:qi + 1], ids[qi])[0]
+        np.testing.assert_array_equal(want.view(np.uint32), dists[qi].view(np.uint32))
+    assert (r["visited_count"] >= 10).all() and (r["dist_cmps"] >= r["visited_count"]).all() and (r["frontier_size"] == 64).all()
+    # same call again, and the same queries in another order
+    r2 = ix.batch_search(Q, k=10, beam=64)
+    for f in ("ids", "dists", "visited_count", "dist_cmps"):
+        np.testing.assert_array_equal(r[f], r2[f])
+    perm = np.random.default_rng(2).permutation(NQ)
+    r3 = ix.batch_search(Q[perm], k=10, beam=64)
+    for f in ("ids", "dists", "visited_count", "dist_cmps"):
+        np.testing.assert_array_equal(r[f][perm], r3[f])
+    # recall against exact ground truth (tie-aware, check_nn_recall.h:83-109)
+    gt, gd = ix.bruteforce_knn(Q, 100)
+    assert (np.diff(gd, axis=1) >= 0).all() and (gd[:, 0] <= dists[:, 0]).all()
+    assert recall_at_k(ids, gt, gd, 10) >= 0.95
+    # bit-exact oracle check of a sample of the queries on the FULL graph
+    G = ix.get_graph()
+    sample = np.sort(np.random.default_rng(3).choice(NQ, 300, replace=False))
+    o = oracle.batch_search(X, G, queries=Q[sample], k=10, beam=64)
+    for f in ("ids", "visited_count", "dist_cmps"):
+        np.testing.assert_array_equal(o[f], r[f][sample], err_msg=f)
+    np.testing.assert_array_equal(o["dists"].view(np.uint32), dists[sample].view(np.uint32))
+    ob = oracle.batch_search(X, G, queries=Q[sample[:60]], k=10, beam=128)
+    rb = ix.batch_search(Q[sample[:60]], k=10, beam=128)
+    for f in ("ids", "visited_count", "dist_cmps"):
+        np.testing.assert_array_equal(ob[f], rb[f], err_msg="beam128 " + f)
+
+
+def test_hcnng_int8_mips_at_scale(oracle):
+    """C5 shape at 1M points (T2I-shaped f32 -> int8, MIPS, HCNNG 30 trees x leaf 1000 x mst_deg 3, all on the device):
+    degree bound, well-formed rows, determinism, recall, and a bit-exact oracle check of sampled queries."""
+    from parlayann_amd import quantize
+    n, nq = 1_000_000, 2000
+    Xf = datasets.t2i_like(n, 200, seed=1234); Qf = datasets.t2i_like(nq, 200, seed=4321)
+    mv = quantize.mips_i8_max_val(Xf, trim=False)
+    X, Q = quantize.mips_i8_translate(Xf, mv), quantize.mips_i8_translate(Qf, mv)
+    del Xf
+    ix = DeviceIndex(X, max_degree=90, metric="mips")
+    ix.hcnng_build(30, 1000, 3, seed=1)
+    G = ix.get_graph()
+    deg = G[:, 0]
+    assert deg.max() <= 90 and deg.min() >= 1 and deg.mean() > 30
+    cols = np.arange(90)[None, :]
+    valid = cols < deg[:, None]
+    nb = G[:, 1:]
+    assert int(nb[valid].max()) < n and not (nb == np.arange(n, dtype=np.uint32)[:, None])[valid].any()
+    r = ix.batch_search(Q, k=10, beam=64)
+    gt, gd = ix.bruteforce_knn(Q, 100)
+    assert recall_at_k(r["ids"], gt, gd, 10) >= 0.9
+    sample = np.arange(0, nq, 10)
+    o = oracle.batch_search(X, G, queries=Q[sample], k=10, beam=64, metric="mips")
+    for f in ("ids", "visited_count", "dist_cmps"):
+        np.testing.assert_array_equal(o[f], r[f][sample], err_msg=f)
+    ix2 = DeviceIndex(X, max_degree=90, metric="mips")
+    ix2.hcnng_build(30, 1000, 3, seed=1)
+    np.testing.assert_array_equal(G, ix2.get_graph())
+    ix.close(); ix2.close()
