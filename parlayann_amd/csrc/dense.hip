@@ -343,6 +343,14 @@ __global__ void __launch_bounds__(256) dense_topk_mfma_f16_kernel(DenseArgs A) {
   for (uint32_t i = tid; i < DT_A * A.mcap; i += 256) lists[i] = KEY_INF;
   if (tid < DT_A) { Aid[tid] = (tid < (int)na_tile && A.a_ids) ? A.a_ids[a0 + tid] : SENTINEL; An[tid] = 0.f; }
   __syncthreads();
+  // m <= 16: lane-parallel top-m as in dense_topk_kernel -- lane (row = lane & 15, quarter = lane >> 4) owns the 16
+  // columns {quarter*16 ..} of every 64-row B tile; K (16 x 4 x 17 words per wave) aliases the B tile between tiles
+  const bool lane_lists = (A.mcap == 16);
+  constexpr int MF_KS = 68;
+  uint64_t TL[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) TL[i] = (i < 16 - (int)A.m) ? 0ull : KEY_INF;
+  uint32_t* Kw = reinterpret_cast<uint32_t*>(Bt) + wave * (DT_AW * MF_KS);
   const uint32_t nseg = (A.pstride + DT_SEG - 1) / DT_SEG;
 
   // stage one 256-byte segment of 64 rows (16 threads x 16 B per row) and add its squared norm
@@ -407,6 +415,41 @@ __global__ void __launch_bounds__(256) dense_topk_mfma_f16_kernel(DenseArgs A) {
     }
     // ---- epilogue: C[row = 4*(lane>>4) + r][col = lane&15] of tile t -> distance, top-m update ----
     const int q = lane >> 4;
+    if (lane_lists) {
+      __syncthreads();                                      // every wave is done reading Bt: reuse it as K
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint32_t row = q * 4 + r, ar = wave * DT_AW + row;
+        const float an = An[ar];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const uint32_t bc = t * 16 + (lane & 15);
+          const uint32_t bid = Bid[bc];
+          float dist;
+          if constexpr (METRIC == PANN_L2) dist = (an + Bn[bc]) - 2.0f * acc[t][r];
+          else dist = -acc[t][r];
+          bool ok = (bc < nb_tile) && (ar < na_tile);
+          if (A.exclude_same_id) ok = ok && (bid != Aid[ar]);
+          Kw[row * MF_KS + t * 17 + (lane & 15)] = ok ? f2ord(dist) : 0xFFFFFFFFu;
+        }
+      }
+      wave_lds_sync();
+      {
+        const uint32_t* krow = Kw + (lane & 15) * MF_KS + (lane >> 4) * 17;
+        const uint32_t* idq = Bid + (lane >> 4) * 16;
+        uint64_t tau = TL[15];
+        uint32_t bits = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) bits |= (krow[j] <= (uint32_t)(tau >> 32) && krow[j] != 0xFFFFFFFFu) ? (1u << j) : 0u;
+        while (bits) {
+          const int j = __ffs(bits) - 1;
+          bits &= bits - 1;
+          const uint64_t x = ((uint64_t)krow[j] << 32) | idq[j];
+          if (x < tau) { tm_chain_insert(TL, x); tau = TL[15]; }
+        }
+      }
+      continue;                                             // the next tile's barrier protects K
+    }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const uint32_t ar = wave * DT_AW + q * 4 + r;          // this lane's A row for register r
@@ -437,6 +480,35 @@ __global__ void __launch_bounds__(256) dense_topk_mfma_f16_kernel(DenseArgs A) {
     }
   }
   __syncthreads();
+  if (lane_lists) {   // rank merge of the four quarter lists of every row (as in dense_topk_kernel); At + Bt hold the lists
+    uint64_t* Lw = reinterpret_cast<uint64_t*>(At) + (size_t)wave * (DT_AW * 4 * 16);
+    const int row = lane & 15, qd = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 16; i++) Lw[(row * 4 + qd) * 16 + i] = TL[i];
+    const uint32_t ar = wave * DT_AW + row;
+    uint64_t* out = A.partial + ((a0 + ar) * A.nsplit + blockIdx.y) * A.m;
+    __syncthreads();
+    const int lead = 16 - (int)A.m;
+    if (ar < na_tile && qd == 0) {
+      int real = 0;
+#pragma unroll
+      for (int o = 0; o < 4; o++) real += (int)tm_lower_bound16(Lw + (row * 4 + o) * 16, KEY_INF) - lead;
+      for (int j = real; j < (int)A.m; j++) out[j] = KEY_INF;
+    }
+    if (ar < na_tile) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const uint64_t x = TL[e];
+        if (e >= lead && x != KEY_INF) {
+          int rank = e - lead;
+#pragma unroll
+          for (int o = 1; o < 4; o++) rank += (int)tm_lower_bound16(Lw + (row * 4 + ((qd + o) & 3)) * 16, x) - lead;
+          if (rank < (int)A.m) out[rank] = x;
+        }
+      }
+    }
+    return;
+  }
   for (uint32_t i = tid; i < na_tile * A.m; i += 256) {
     const uint32_t ar = i / A.m, j = i % A.m;
     A.partial[((a0 + ar) * A.nsplit + blockIdx.y) * A.m + j] = lists[(size_t)ar * A.mcap + j];
