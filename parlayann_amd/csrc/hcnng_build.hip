@@ -35,12 +35,20 @@ static inline uint64_t hc_mix_host(uint64_t x) {
 
 struct SplitCluster { uint32_t lo, len, pa, pb; };   // pa/pb: POSITIONS of the two pivots in the ids array
 
+// tile t of a level belongs to the cluster c with tile_base[c] <= t < tile_base[c+1] (clusters in position order,
+// ceil(len/64) tiles each); the host uploads only the ncl+1 prefix sums
+__device__ __forceinline__ uint32_t tile_cluster(const uint32_t* tile_base, uint32_t ncl, uint32_t t) {
+  uint32_t lo = 0, hi = ncl;            // invariant: tile_base[lo] <= t < tile_base[hi]
+  while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tile_base[mid] <= t) lo = mid; else hi = mid; }
+  return lo;
+}
+
 // side[pos] = 0 when d(ids[pos], pivot_a) <= d(ids[pos], pivot_b)   (clusterEdge.h:71-83); also flags
 // clusters whose two pivot vectors are identical (:107)
 template <int DT, int METRIC, int LPC, bool NCH1>
 __global__ void __launch_bounds__(PANN_WAVE) tree_split_kernel(PointsView pv, uint32_t dbytes, const uint32_t* ids,
-                                                               const SplitCluster* cl, const uint32_t* tile_cl,
-                                                               const uint32_t* tile_off, uint32_t* is_first,
+                                                               const SplitCluster* cl, const uint32_t* tile_base,
+                                                               uint32_t ncl, uint32_t* is_first,
                                                                uint32_t* same_flag) {
   const int lane = threadIdx.x;
   __shared__ uint32_t Pl[PANN_WAVE];
@@ -48,8 +56,9 @@ __global__ void __launch_bounds__(PANN_WAVE) tree_split_kernel(PointsView pv, ui
   extern __shared__ __align__(16) uint8_t smem[];
   uint4* qlds = reinterpret_cast<uint4*>(smem);
   const uint32_t t = blockIdx.x;
-  const SplitCluster c = cl[tile_cl[t]];
-  const uint32_t off = tile_off[t];
+  const uint32_t ci = tile_cluster(tile_base, ncl, t);
+  const SplitCluster c = cl[ci];
+  const uint32_t off = (t - tile_base[ci]) * PANN_WAVE;
   const uint32_t mm = min(c.len - off, (uint32_t)PANN_WAVE);
   const uint32_t ida = ids[c.pa], idb = ids[c.pb];
   if (lane < (int)mm) Pl[lane] = ids[c.lo + off + lane];
@@ -62,7 +71,7 @@ __global__ void __launch_bounds__(PANN_WAVE) tree_split_kernel(PointsView pv, ui
       diff |= (x.x != y.x) | (x.y != y.y) | (x.z != y.z) | (x.w != y.w);
     }
     const uint64_t dm = __ballot(diff);
-    if (lane == 0) same_flag[tile_cl[t]] = dm ? 0u : 1u;
+    if (lane == 0) same_flag[ci] = dm ? 0u : 1u;
   }
   QReg<DT> qreg{};
   load_query<DT, LPC, NCH1>(pv.points + (uint64_t)ida * pv.pstride, pv.pstride, pv.nch, qreg, qlds, lane);
@@ -86,10 +95,11 @@ struct ScatterCluster { uint32_t lo, len, n0, half; };
 // stable partition of every splitting cluster: first-side members keep their order at [lo, lo+n0),
 // the others at [lo+n0, lo+len); "halved" clusters (:108-115) and finished clusters do not move
 __global__ void tree_scatter_kernel(const uint32_t* ids, uint32_t* newids, const uint32_t* is_first, const uint32_t* scan0,
-                                    const ScatterCluster* cl, const uint32_t* tile_cl, const uint32_t* tile_off) {
+                                    const ScatterCluster* cl, const uint32_t* tile_base, uint32_t ncl) {
   const uint32_t t = blockIdx.x;
-  const ScatterCluster c = cl[tile_cl[t]];
-  const uint32_t i = tile_off[t] + threadIdx.x;
+  const uint32_t ci = tile_cluster(tile_base, ncl, t);
+  const ScatterCluster c = cl[ci];
+  const uint32_t i = (t - tile_base[ci]) * PANN_WAVE + threadIdx.x;
   if (i >= c.len) return;
   const uint32_t pos = c.lo + i;
   uint32_t np = pos;
@@ -107,6 +117,10 @@ __global__ void fill_u32(uint32_t* p, uint64_t n, uint32_t v) {
 __global__ void iota_u32(uint32_t* p, uint64_t n) {
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   if (i < n) p[i] = (uint32_t)i;
+}
+__global__ void iota_mod_u32(uint32_t* p, uint64_t total, uint32_t n) {      // ids of every tree of a forest: 0..n-1 repeated
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (i < total) p[i] = (uint32_t)(i % n);
 }
 __global__ void invert_perm(const uint32_t* ids, uint32_t* pos, uint64_t n) {
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -297,13 +311,19 @@ int hcnng_build_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, uint32
   const size_t qb = query_lds_bytes(ix);
   const uint32_t nb256 = (uint32_t)((n + 255) / 256);
 
+  // The cluster trees are independent (clusterEdge.h:146-153): all trees of a group are split level by level
+  // TOGETHER -- one ids array of group*n positions, clusters of every tree in one launch -- so a level costs one
+  // host round trip for the whole forest instead of one per tree.  Positions are 32-bit: group*n < 2^31.
+  uint32_t group = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(num_clusters, (1ull << 31) / std::max<uint64_t>(n, 1)));
+  if (const char* g = getenv("PANN_HCNNG_GROUP")) group = std::max<uint32_t>(1, std::min<uint32_t>(group, (uint32_t)atoi(g)));   // test hook: smaller forests
+  const uint64_t gn = (uint64_t)group * n;
   HBuf b_ids, b_new, b_first, b_scan, b_pos, b_deg, b_leaflo, b_nnids, b_nnd, b_ka, b_kb, b_par, b_rnk, b_dgr, b_tmp;
   size_t scan_tmp = 0, sort_tmp = 0;
-  (void)rocprim::exclusive_scan(nullptr, scan_tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st);
+  (void)rocprim::exclusive_scan(nullptr, scan_tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)gn + 1, rocprim::plus<uint32_t>(), st);
   (void)rocprim::segmented_radix_sort_keys(nullptr, sort_tmp, (uint64_t*)nullptr, (uint64_t*)nullptr, (unsigned)(n * m), (unsigned)(n / 2 + 2),
                                            (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0, 64, st);
   if (n * m >= 0xFFFFFFF0ull) { set_error("pann_hcnng_build: n too large for 32-bit edge offsets"); return PANN_ERR_BAD_ARG; }
-  if (b_ids.alloc(n * 4) || b_new.alloc(n * 4) || b_first.alloc((n + 1) * 4) || b_scan.alloc((n + 1) * 4) || b_pos.alloc(n * 4) ||
+  if (b_ids.alloc(gn * 4) || b_new.alloc(gn * 4) || b_first.alloc((gn + 1) * 4) || b_scan.alloc((gn + 1) * 4) || b_pos.alloc(n * 4) ||
       b_deg.alloc(n * 4) || b_leaflo.alloc(n * 4) || b_nnids.alloc(n * m * 4) || b_nnd.alloc(n * m * 4) || b_ka.alloc(n * m * 8) ||
       b_kb.alloc(n * m * 8) || b_par.alloc(n * 4) || b_rnk.alloc(n) || b_dgr.alloc(n) || b_tmp.alloc(std::max(scan_tmp, sort_tmp) + 256)) {
     set_error("pann_hcnng_build: hipMalloc failed"); return PANN_ERR_HIP;
@@ -312,23 +332,27 @@ int hcnng_build_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, uint32
   PANN_HIP(hipGetLastError());
 
   // per-level buffers, sized once for the worst level: clusters that still split are longer than cluster_size
-  const size_t ncl_cap = (size_t)(n / cluster_size) + 2, nt_cap = (size_t)(n / 64) + ncl_cap + 2;
-  HBuf d_sc, d_tcl, d_toff, d_same, d_scat, d_n0;
-  if (d_sc.alloc(ncl_cap * sizeof(SplitCluster)) || d_tcl.alloc(nt_cap * 4) || d_toff.alloc(nt_cap * 4) || d_same.alloc(ncl_cap * 4) ||
+  const size_t ncl_cap = (size_t)(gn / cluster_size) + 2 * group + 2;
+  HBuf d_sc, d_tbase, d_same, d_scat, d_n0;
+  if (d_sc.alloc(ncl_cap * sizeof(SplitCluster)) || d_tbase.alloc((ncl_cap + 1) * 4) || d_same.alloc(ncl_cap * 4) ||
       d_scat.alloc(ncl_cap * sizeof(ScatterCluster)) || d_n0.alloc(ncl_cap * 4)) { set_error("pann_hcnng_build: hipMalloc failed"); return PANN_ERR_HIP; }
   struct Cl { uint32_t lo, len; uint64_t rnd; };
   double t_tree = 0, t_leaf = 0, t_mst = 0;
-  for (uint32_t t = 0; t < num_clusters; t++) {
-    const auto t0 = now();
-    uint32_t* ids = b_ids.as<uint32_t>();
-    uint32_t* newids = b_new.as<uint32_t>();
-    hipLaunchKernelGGL(iota_u32, dim3(nb256), dim3(256), 0, st, ids, n);
-    std::vector<Cl> level = {Cl{0, (uint32_t)n, hc_mix_host(hc_mix_host(seed + t))}};
-    std::vector<uint64_t> leaf_off;                       // leaf start positions (sorted at the end)
+  for (uint32_t tg = 0; tg < num_clusters; tg += group) {
+   const uint32_t ng = std::min(group, num_clusters - tg);            // trees tg .. tg+ng-1 in this forest
+   const auto tf0 = now();
+   uint32_t* fids = b_ids.as<uint32_t>();
+   uint32_t* fnew = b_new.as<uint32_t>();
+   std::vector<std::vector<uint64_t>> forest_leaves(ng);              // leaf start positions per tree (local to the tree)
+   {
+    const uint64_t tot = (uint64_t)ng * n;
+    hipLaunchKernelGGL(iota_mod_u32, dim3((uint32_t)((tot + 255) / 256)), dim3(256), 0, st, fids, tot, (uint32_t)n);
+    std::vector<Cl> level;
+    for (uint32_t j = 0; j < ng; j++) level.push_back(Cl{(uint32_t)(j * n), (uint32_t)n, hc_mix_host(hc_mix_host(seed + tg + j))});
     while (!level.empty()) {
       std::vector<SplitCluster> sc; std::vector<Cl> src;
       for (const Cl& c : level) {
-        if (c.len <= cluster_size) { leaf_off.push_back(c.lo); continue; }            // clusterEdge.h:103-104
+        if (c.len <= cluster_size) { forest_leaves[c.lo / n].push_back(c.lo % n); continue; }   // clusterEdge.h:103-104
         const uint64_t fi = hc_mix_host(c.rnd + 0) % c.len;                            // select_two_random :40-50
         const uint64_t su = hc_mix_host(c.rnd + 1) % (c.len - 1);
         const uint64_t si = su < fi ? su : su + 1;
@@ -336,21 +360,22 @@ int hcnng_build_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, uint32
         src.push_back(c);
       }
       if (sc.empty()) break;
-      std::vector<uint32_t> tile_cl, tile_off;
-      for (size_t ci = 0; ci < sc.size(); ci++)
-        for (uint32_t o = 0; o < sc[ci].len; o += 64) { tile_cl.push_back((uint32_t)ci); tile_off.push_back(o); }
-      const size_t nt = tile_cl.size(), ncl = sc.size();
-      if (ncl > ncl_cap || nt > nt_cap) { set_error("pann_hcnng_build: internal level buffer overflow"); return PANN_ERR_OVERFLOW; }
+      const size_t ncl = sc.size();
+      if (ncl > ncl_cap) { set_error("pann_hcnng_build: internal level buffer overflow"); return PANN_ERR_OVERFLOW; }
+      std::vector<uint32_t> tile_base(ncl + 1);
+      uint64_t ntiles = 0;
+      for (size_t ci = 0; ci < ncl; ci++) { tile_base[ci] = (uint32_t)ntiles; ntiles += (sc[ci].len + 63) / 64; }
+      tile_base[ncl] = (uint32_t)ntiles;
+      const size_t nt = (size_t)ntiles;
       PANN_HIP(hipMemcpyAsync(d_sc.p, sc.data(), ncl * sizeof(SplitCluster), hipMemcpyHostToDevice, st));
-      PANN_HIP(hipMemcpyAsync(d_tcl.p, tile_cl.data(), nt * 4, hipMemcpyHostToDevice, st));
-      PANN_HIP(hipMemcpyAsync(d_toff.p, tile_off.data(), nt * 4, hipMemcpyHostToDevice, st));
-      PANN_HIP(hipMemsetAsync(b_first.p, 0, (n + 1) * 4, st));
-#define CALL_TS(DT, MT, L, N1) hipLaunchKernelGGL((tree_split_kernel<DT, MT, L, N1>), dim3((uint32_t)nt), dim3(PANN_WAVE), qb, st, pv, ix.dbytes, ids, d_sc.as<SplitCluster>(), d_tcl.as<uint32_t>(), d_toff.as<uint32_t>(), b_first.as<uint32_t>(), d_same.as<uint32_t>())
+      PANN_HIP(hipMemcpyAsync(d_tbase.p, tile_base.data(), (ncl + 1) * 4, hipMemcpyHostToDevice, st));
+      PANN_HIP(hipMemsetAsync(b_first.p, 0, (tot + 1) * 4, st));
+#define CALL_TS(DT, MT, L, N1) hipLaunchKernelGGL((tree_split_kernel<DT, MT, L, N1>), dim3((uint32_t)nt), dim3(PANN_WAVE), qb, st, pv, ix.dbytes, fids, d_sc.as<SplitCluster>(), d_tbase.as<uint32_t>(), (uint32_t)ncl, b_first.as<uint32_t>(), d_same.as<uint32_t>())
       PANN_TYPE_SWITCH(ix, CALL_TS);
 #undef CALL_TS
       PANN_HIP(hipGetLastError());
       size_t tb = scan_tmp;
-      PANN_HIP(rocprim::exclusive_scan(b_tmp.p, tb, b_first.as<uint32_t>(), b_scan.as<uint32_t>(), 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), st));
+      PANN_HIP(rocprim::exclusive_scan(b_tmp.p, tb, b_first.as<uint32_t>(), b_scan.as<uint32_t>(), 0u, (size_t)tot + 1, rocprim::plus<uint32_t>(), st));
       // per-cluster first-side counts and identical-pivot flags back to the host (a few KB)
       std::vector<uint32_t> h_same(ncl), h_n0(ncl);
       hipLaunchKernelGGL(cluster_counts_kernel, dim3((uint32_t)((ncl + 255) / 256)), dim3(256), 0, st, b_scan.as<uint32_t>(),
@@ -371,18 +396,24 @@ int hcnng_build_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, uint32
         next.push_back(Cl{sc[ci].lo + n0, sc[ci].len - n0, hc_mix_host(hc_mix_host(r) + 1 + 17)});
       }
       PANN_HIP(hipMemcpyAsync(d_scat.p, scat.data(), ncl * sizeof(ScatterCluster), hipMemcpyHostToDevice, st));
-      PANN_HIP(hipMemcpyAsync(newids, ids, n * 4, hipMemcpyDeviceToDevice, st));      // finished clusters keep their place
-      hipLaunchKernelGGL(tree_scatter_kernel, dim3((uint32_t)nt), dim3(64), 0, st, ids, newids, b_first.as<uint32_t>(),
-                         b_scan.as<uint32_t>(), d_scat.as<ScatterCluster>(), d_tcl.as<uint32_t>(), d_toff.as<uint32_t>());
+      PANN_HIP(hipMemcpyAsync(fnew, fids, tot * 4, hipMemcpyDeviceToDevice, st));     // finished clusters keep their place
+      hipLaunchKernelGGL(tree_scatter_kernel, dim3((uint32_t)nt), dim3(64), 0, st, fids, fnew, b_first.as<uint32_t>(),
+                         b_scan.as<uint32_t>(), d_scat.as<ScatterCluster>(), d_tbase.as<uint32_t>(), (uint32_t)ncl);
       PANN_HIP(hipGetLastError());
       PANN_HIP(hipStreamSynchronize(st));   // the host vectors of this level go out of scope
-      std::swap(ids, newids);
+      std::swap(fids, fnew);
       level.swap(next);
     }
+   }
+   t_tree += secs(tf0, now());
+   for (uint32_t j = 0; j < ng; j++) {
+    const auto t0 = now();
+    const auto t1 = t0;
+    uint32_t* ids = fids + (size_t)j * n;
+    std::vector<uint64_t>& leaf_off = forest_leaves[j];
     std::sort(leaf_off.begin(), leaf_off.end());
     leaf_off.push_back(n);
     const uint32_t nleaves = (uint32_t)leaf_off.size() - 1;
-    const auto t1 = now();
 
     // ---- all-pairs 10-NN of every leaf (device ids, no host copy) ----
     std::vector<uint32_t> tseg, ta0;
@@ -424,7 +455,8 @@ int hcnng_build_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, uint32
     PANN_HIP(hipGetLastError());
     PANN_HIP(hipStreamSynchronize(st));
     const auto t3 = now();
-    t_tree += secs(t0, t1); t_leaf += secs(t1, t2); t_mst += secs(t2, t3);
+    t_leaf += secs(t1, t2); t_mst += secs(t2, t3);
+   }
   }
   if (times3) { times3[0] = t_tree; times3[1] = t_leaf; times3[2] = t_mst; }
   return PANN_OK;

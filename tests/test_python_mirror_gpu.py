@@ -191,6 +191,15 @@ def test_hcnng_build_leaf_size_extremes(oracle, n, clusters, leaf, mst_deg):
     np.testing.assert_array_equal(G, Go)
 
 
+def test_hcnng_forest_groups_give_the_same_graph(oracle, monkeypatch):
+    """trees are split level by level in groups (all of them when group * n < 2^31); the grouping must not matter"""
+    X = datasets.sift_like(4000, 64, seed=3, dtype=np.uint8)
+    Go = oracle.hcnng_build(X, 5, 150, 3, seed=4)
+    for g in ("1", "2", "5"):
+        monkeypatch.setenv("PANN_HCNNG_GROUP", g)
+        np.testing.assert_array_equal(wrapper.hcnng_build(X, "Euclidian", 5, 150, 3, seed=4), Go)
+
+
 def test_parlayannpy_dropin_names():
     from parlayann_amd import _ParlayANNpy as m
     for cls in ("FloatEuclidianIndex", "FloatMipsIndex", "UInt8EuclidianIndex", "UInt8MipsIndex", "Int8EuclidianIndex",
