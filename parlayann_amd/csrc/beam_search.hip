@@ -184,19 +184,32 @@ __device__ __forceinline__ bool filter_update(uint32_t* H, uint32_t hmask, bool 
 
 // Distances from the query to the m ids in Pl[0..m); survivors of `dist < cutoff` (:157) are
 // appended to C in row order.
-template <int DT, int METRIC, int LPC, bool NCH1, int U>
+template <int DT, int METRIC, int LPC, bool NCH1, int U, bool BATCH_EMIT = true>
 __device__ __forceinline__ uint32_t gather_distances(const BSParams& P, const QReg<DT>& qreg,
                                                      const uint4* qlds, const uint32_t* Pl, uint32_t m,
                                                      uint32_t cutoff_ord, uint64_t* C, uint32_t c, int lane) {
   const PointsView PV{P.points, P.pstride, P.nch, P.exact};
-  gather_tile<DT, METRIC, LPC, NCH1, U>(PV, qreg, qlds, Pl, m, lane,
-    [&](bool has, uint32_t, uint32_t id, float dist) {
-      const uint32_t ord = f2ord(dist);
-      const bool pass = has && (ord < cutoff_ord);
-      const uint64_t pm = __ballot(pass);
-      if (pass) C[c + lanes_below(pm, lane)] = ((uint64_t)ord << 32) | id;
-      c += __popcll(pm);
-    });
+  if constexpr (BATCH_EMIT) {
+    // one append per gather iteration (G*U candidates): +4 % on the beam-64 kernel at 10K queries
+    gather_tile<DT, METRIC, LPC, NCH1, U>(PV, qreg, qlds, Pl, m, lane,
+      [&](bool has, uint32_t, uint32_t id, float dist, uint64_t before) {
+        const uint32_t ord = f2ord(dist);
+        const bool pass = has && (ord < cutoff_ord);
+        const uint64_t pm = __ballot(pass);
+        if (pass) C[c + (uint32_t)__popcll(pm & before)] = ((uint64_t)ord << 32) | id;
+        c += __popcll(pm);
+      });
+  } else {
+    // one append per candidate group (the beam-128 kernel measured 2.5 % slower with the batched form)
+    gather_tile<DT, METRIC, LPC, NCH1, U>(PV, qreg, qlds, Pl, m, lane,
+      [&](bool has, uint32_t, uint32_t id, float dist) {
+        const uint32_t ord = f2ord(dist);
+        const bool pass = has && (ord < cutoff_ord);
+        const uint64_t pm = __ballot(pass);
+        if (pass) C[c + lanes_below(pm, lane)] = ((uint64_t)ord << 32) | id;
+        c += __popcll(pm);
+      });
+  }
   return c;
 }
 
@@ -715,7 +728,7 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
     (void)filter_update<HASH_LDS>(H, hmask, act, a, lane, T, hb);
     if (act) Pl[lane] = a;
     PANN_WSYNC();
-    c = gather_distances<DT, METRIC, LPC, NCH1, 4>(P, qreg, qlds, Pl, P.nstarts, 0xFFFFFFFFu, C, c, lane);
+    c = gather_distances<DT, METRIC, LPC, NCH1, 4, false>(P, qreg, qlds, Pl, P.nstarts, 0xFFFFFFFFu, C, c, lane);
     PANN_WSYNC();
   }
 
@@ -784,7 +797,7 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
           pref_id = next_id;
           pref_row = (lane < (int)P.gstride) ? P.graph[(size_t)next_id * P.gstride + lane] : SENTINEL;
         }
-        if (m) c = gather_distances<DT, METRIC, LPC, NCH1, PANN_GU_B128(LPC, NCH1)>(P, qreg, qlds, Pl, m, cutoff_ord, C, c, lane);
+        if (m) c = gather_distances<DT, METRIC, LPC, NCH1, PANN_GU_B128(LPC, NCH1), false>(P, qreg, qlds, Pl, m, cutoff_ord, C, c, lane);
         PANN_WSYNC();
         PANN_STAMP(3);
       }

@@ -1,6 +1,7 @@
 // pann_device.h -- device helpers shared by the gfx950 kernels: the visited-filter hash, the
 // (dist,id) sort key, DPP lane-group reductions and the per-dtype distance accumulators.
 #pragma once
+#include <type_traits>
 #include "pann_internal.h"
 
 namespace pann {
@@ -303,12 +304,29 @@ __device__ __forceinline__ void gather_iter(const PointsView& PV, const QReg<DT>
       }
     }
   }
+  if constexpr (std::is_invocable_v<Emit&, bool, uint32_t, uint32_t, float, uint64_t>) {
+    // ONE emit for the G*U candidates of the iteration: after the butterfly every lane of a group holds the group's U
+    // results, lane `sub` (< U) presents result `sub`.  The fifth argument is the set of lanes that hold a candidate
+    // with a SMALLER index (u-major order), so an ordered append is position = base + popcount(pass_mask & before).
+    float dsel = 0.0f; uint32_t isel = 0;
 #pragma unroll
-  for (int u = 0; u < U; u++) {
-    const auto tot = group_sum<LPC>(acc_lane_value<DT, METRIC>(acc[u]));
-    const float dist = dist_finish<DT, METRIC>(tot);
-    const uint32_t ci = s0 + u * G + grp;
-    emit((sub == 0) && (ci < m), ci, ids[u], dist);
+    for (int u = 0; u < U; u++) {
+      const float dist = dist_finish<DT, METRIC>(group_sum<LPC>(acc_lane_value<DT, METRIC>(acc[u])));
+      if (sub == u) { dsel = dist; isel = ids[u]; }
+    }
+    constexpr uint64_t REP = LPC == 4 ? 0x1111111111111111ull : LPC == 8 ? 0x0101010101010101ull
+                           : LPC == 16 ? 0x0001000100010001ull : LPC == 32 ? 0x0000000100000001ull : 1ull;
+    const uint64_t before = REP * ((1ull << sub) - 1ull) | ((REP << sub) & ((1ull << (grp * LPC)) - 1ull));
+    const uint32_t ci = s0 + (uint32_t)sub * G + grp;
+    emit((sub < U) && (ci < m), ci, isel, dsel, before);
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const auto tot = group_sum<LPC>(acc_lane_value<DT, METRIC>(acc[u]));
+      const float dist = dist_finish<DT, METRIC>(tot);
+      const uint32_t ci = s0 + u * G + grp;
+      emit((sub == 0) && (ci < m), ci, ids[u], dist);
+    }
   }
 }
 
@@ -340,7 +358,10 @@ __device__ __forceinline__ void gather_tile(const PointsView& PV, const QReg<DT>
         float acc = 0.0f;
         for (uint32_t ch = 0; ch < nchunks; ch++)
           dist_accum_exact<DT, METRIC>(acc, *reinterpret_cast<const uint4*>(row + ch * 16), qlds[ch]);
-        emit(ci < m, ci, id, METRIC == PANN_MIPS ? -acc : acc);
+        if constexpr (std::is_invocable_v<Emit&, bool, uint32_t, uint32_t, float, uint64_t>)
+          emit(ci < m, ci, id, METRIC == PANN_MIPS ? -acc : acc, (1ull << lane) - 1ull);   // lane order is candidate order
+        else
+          emit(ci < m, ci, id, METRIC == PANN_MIPS ? -acc : acc);
       }
       return;
     }
