@@ -63,6 +63,24 @@ __device__ __forceinline__ T group_sum(T v) {
   return v;
 }
 
+// the same butterfly for U independent values, step by step across all of them: a DPP operand must have been
+// written two cycles earlier, and the other chains fill those slots (the one-value form costs an s_nop per step)
+template <int LPC, int U, typename T>
+__device__ __forceinline__ void group_sum_multi(T (&v)[U]) {
+#pragma unroll
+  for (int u = 0; u < U; u++) if (LPC >= 2) v[u] = dpp_step<0xB1>(v[u]);
+#pragma unroll
+  for (int u = 0; u < U; u++) if (LPC >= 4) v[u] = dpp_step<0x4E>(v[u]);
+#pragma unroll
+  for (int u = 0; u < U; u++) if (LPC >= 8) v[u] = dpp_step<0x141>(v[u]);
+#pragma unroll
+  for (int u = 0; u < U; u++) if (LPC >= 16) v[u] = dpp_step<0x140>(v[u]);
+#pragma unroll
+  for (int u = 0; u < U; u++) if (LPC >= 32) v[u] = xlane_add(v[u], __shfl_xor(v[u], 16));
+#pragma unroll
+  for (int u = 0; u < U; u++) if (LPC >= 64) v[u] = xlane_add(v[u], __shfl_xor(v[u], 32));
+}
+
 // ---- distance accumulators.  One dist_accum call consumes 16 bytes of a base row and the
 // matching 16 bytes of the query (held pre-digested in a QReg).  Integer types are exact in int32
 // (euclidian_point.h:54-62,74-81; mips_point.h:43-57); float types accumulate in f32: each lane
@@ -309,9 +327,13 @@ __device__ __forceinline__ void gather_iter(const PointsView& PV, const QReg<DT>
     // results, lane `sub` (< U) presents result `sub`.  The fifth argument is the set of lanes that hold a candidate
     // with a SMALLER index (u-major order), so an ordered append is position = base + popcount(pass_mask & before).
     float dsel = 0.0f; uint32_t isel = 0;
+    typename AccT<DT>::type tot[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) tot[u] = acc_lane_value<DT, METRIC>(acc[u]);
+    group_sum_multi<LPC, U>(tot);
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const float dist = dist_finish<DT, METRIC>(group_sum<LPC>(acc_lane_value<DT, METRIC>(acc[u])));
+      const float dist = dist_finish<DT, METRIC>(tot[u]);
       if (sub == u) { dsel = dist; isel = ids[u]; }
     }
     constexpr uint64_t REP = LPC == 4 ? 0x1111111111111111ull : LPC == 8 ? 0x0101010101010101ull
