@@ -44,7 +44,7 @@ namespace pann {
 #define PANN_MINWAVES 1
 #endif
 #ifndef PANN_MINWAVES_B64
-#define PANN_MINWAVES_B64 7   /* <= 72 VGPRs: 7 waves per SIMD = 28 queries per CU (6, 7 and 8 measure the same) */
+#define PANN_MINWAVES_B64 7   /* at least 7 waves per SIMD (<= 72 VGPRs); the kernel uses 61 -> 8 waves, LDS caps a CU at 30 queries */
 #endif
 #ifdef PANN_STAMPS
 #define PANN_STAMP(slot)                                                                        \
