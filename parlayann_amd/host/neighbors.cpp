@@ -6,6 +6,7 @@
 // -self 1 -range 1 -radius -radius_2 [-use_existing 1]  (vamana/neighbors.h:86-104)
 // -quantize_bits 8 with -data_type float  (neighborsTime.C:157-164,190-197)
 // -quantize_mode 1 [-rerank_factor 100] with -data_type float  (vamana/neighbors.h:117-147)
+// -two_pass 1 (= -num_passes 2), -normalize 1 (float data)  (neighborsTime.C:104-106,113,147-153)
 #include <cstring>
 #include <map>
 #include <string>
@@ -36,7 +37,13 @@ int run(const Args& a) {
   const char* base = a.str("-base_path");
   if (!base) { std::cout << "usage: neighbors -base_path <b> [-graph_path <g>] [-query_path <q> -gt_path <gt>] ..." << std::endl; return 1; }
   PR Points(base);
-  if (a.str("-query_path")) { PR Queries(a.str("-query_path")); return run_on<Point>(a, Points, &Queries); }
+  const bool norm = a.num("-normalize", 0) != 0;                                   // neighborsTime.C:113,147-153 (float only)
+  if constexpr (std::is_same<typename Point::T, float>::value) { if (norm) { std::cout << "normalizing data" << std::endl; normalize_range(Points); } }
+  if (a.str("-query_path")) {
+    PR Queries(a.str("-query_path"));
+    if constexpr (std::is_same<typename Point::T, float>::value) { if (norm) normalize_range(Queries); }
+    return run_on<Point>(a, Points, &Queries);
+  }
   return run_on<Point>(a, Points, nullptr);
 }
 
@@ -81,7 +88,7 @@ int run_quantize_mode(const Args& a) {
   if constexpr (MIPS) mv = generate_max_val_mips_i8(Points, true); else pm = generate_parameters_u8(Points);
   QPR Q_Points = quant(Points);
   const long k = a.num("-k", 10), Q = a.num("-Q", 0);
-  BuildParams BP(a.num("-R", 64), a.num("-L", 128), a.flt("-alpha", 1.2), (int)a.num("-num_passes", 1));
+  BuildParams BP(a.num("-R", 64), a.num("-L", 128), a.flt("-alpha", 1.2), (int)(a.num("-two_pass", 0) == 1 ? 2 : a.num("-num_passes", 1)));
   Graph<indexType> G;
   if (a.str("-graph_path")) {
     G = Graph<indexType>(a.str("-graph_path"));
@@ -111,7 +118,7 @@ int run_on(const Args& a, PointRange<Point>& Points, PointRange<Point>* QueriesI
   const long k = a.num("-k", 10), Q = a.num("-Q", 0);            // 0: sweep (neighborsTime.C: -Q default 0)
   BuildParams BP;
   if (alg == "hcnng") BP = BuildParams(a.num("-num_clusters", 30), a.num("-cluster_size", 1000), a.num("-mst_deg", 3));
-  else BP = BuildParams(a.num("-R", 64), a.num("-L", 128), a.flt("-alpha", 1.2), (int)a.num("-num_passes", 1));
+  else BP = BuildParams(a.num("-R", 64), a.num("-L", 128), a.flt("-alpha", 1.2), (int)(a.num("-two_pass", 0) == 1 ? 2 : a.num("-num_passes", 1)));
   Graph<indexType> G;
   if (a.str("-graph_path")) {
     G = Graph<indexType>(a.str("-graph_path"));

@@ -102,4 +102,20 @@ PointRange<Mips_Point<int8_t>> quantize_mips_i8(const FloatRange& pr, float max_
   return PointRange<Mips_Point<int8_t>>(q.data(), pr.size(), (unsigned int)d);
 }
 
+// Point::normalize for every row of a float range (mips_point.h:113-122, euclidian_point.h:150-158; `-normalize`,
+// neighborsTime.C:147-153): norm accumulated in double over float products, inverse taken in float
+template <class FloatRange>
+void normalize_range(FloatRange& pr) {
+  const long d = pr.dimension();
+  for (size_t i = 0; i < pr.size(); i++) {
+    float* v = (float*)pr.location((long)i);
+    double norm = 0.0;
+    for (long j = 0; j < d; j++) norm += v[j] * v[j];
+    norm = std::sqrt(norm);
+    if (norm == 0) norm = 1.0;
+    const float inv_norm = (float)(1.0 / norm);
+    for (long j = 0; j < d; j++) v[j] = v[j] * inv_norm;
+  }
+}
+
 }  // namespace parlayANN

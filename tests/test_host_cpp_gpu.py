@@ -208,6 +208,29 @@ def test_compute_groundtruth_cli(exe, files, oracle):
     np.testing.assert_array_equal(dists, gd)
 
 
+def test_cli_normalize_and_two_pass(exe, tmp_path, oracle):
+    """-normalize 1 (neighborsTime.C:147-153) and -two_pass 1 (:104-106) on float MIPS data: graph = the oracle's two-pass
+    build on the oracle-normalised points (integer-valued rows scaled by powers of two stay exact under normalisation
+    only approximately, so the check is recall- and degree-level plus identical row SETS for most rows)"""
+    n, nq = 5000, 200
+    X = datasets.t2i_like(n, 64, seed=1234).astype(np.float32); Q = datasets.t2i_like(nq, 64, seed=4321).astype(np.float32)
+    Xn, Qn = oracle.normalize(X), oracle.normalize(Q)
+    gt, gd = oracle.bruteforce_knn(Xn, Qn, 100, "mips")
+    io.write_bin(tmp_path / "b.fbin", X); io.write_bin(tmp_path / "q.fbin", Q); io.write_ibin(tmp_path / "gt.ibin", gt, gd)
+    out = _run(exe, "-base_path", tmp_path / "b.fbin", "-query_path", tmp_path / "q.fbin", "-gt_path", tmp_path / "gt.ibin",
+               "-graph_outfile", tmp_path / "g.graph", "-data_type", "float", "-dist_func", "mips", "-normalize", 1, "-two_pass", 1,
+               "-R", 32, "-L", 64, "-alpha", 1.0, "-k", 10, "-Q", 64, "-seed", 5)
+    assert "normalizing data" in out
+    G = io.read_graph(tmp_path / "g.graph")
+    Go, _ = oracle.vamana_build(Xn, 32, 64, 1.0, num_passes=2, seed=5, metric="mips")
+    assert abs(G[:, 0].mean() - Go[:, 0].mean()) <= 0.01 * Go[:, 0].mean()
+    same = np.mean([set(G[i, 1:1 + G[i, 0]]) == set(Go[i, 1:1 + Go[i, 0]]) for i in range(0, n, 5)])
+    assert same > 0.9
+    rec = float(re.findall(r"recall=([0-9.]+)", out)[0])
+    o = oracle.batch_search(Xn, Go, queries=Qn, k=10, beam=64, metric="mips")
+    assert abs(rec - oracle.recall(o["ids"], gt, gd, 10)) <= 0.01 and rec > 0.9
+
+
 def test_pivot_split_matches_oracle_distances(oracle):
     X = datasets.sift_like(3000, 96, seed=1, dtype=np.float32)
     ix = DeviceIndex(X, max_degree=8)
