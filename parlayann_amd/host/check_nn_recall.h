@@ -2,9 +2,11 @@
 // QPS at recall the reference's way: checkRecall (:17-125: time only the batched search, tie-aware
 // recall :83-109, QPS :110), the sweep of search_and_parse (:181-268: 43 beam widths, 20 visit limits, one
 // "best accuracy" point) and the best-QPS-per-recall-bucket table of parse_result (parse_results.h:192-218).
-// The CSV writer (:127-158) is out of scope.
+// write_to_csv (:127-158, format of utils/csvfile.h: comma separated, strings quoted, appended to the file).
 #pragma once
 #include <chrono>
+#include <fstream>
+#include <string>
 #include <set>
 
 #include "beam_search.h"
@@ -103,9 +105,45 @@ inline std::pair<std::vector<nn_result>, std::vector<float>> parse_result(const 
   return {best, kept};
 }
 
+// what the report says about the graph (parse_results.h:35-58)
+struct Graph_ {
+  std::string name, params; long size = 0; double avg_deg = 0; int max_deg = 0; double time = 0;
+  void print() const {
+    std::cout << name << " graph built with " << size << " points and parameters " << params << std::endl;
+    std::cout << "Graph has average degree " << avg_deg << " and maximum degree " << max_deg << std::endl;
+    std::cout << "Graph built in " << time << " seconds" << std::endl;
+  }
+};
+
+// write_to_csv (:127-158): graph block, blank row, one row per recall bucket, two blank rows; the file is appended to
+inline void write_to_csv(const std::string& csv_filename, const std::vector<float>& buckets, const std::vector<nn_result>& results,
+                         const Graph_& G) {
+  std::ofstream f(csv_filename, std::ios::app);
+  if (!f.is_open()) { std::cout << "ERROR: cannot open " << csv_filename << std::endl; abort(); }
+  auto q = [](const std::string& v) {                      // strings are quoted, embedded quotes doubled
+    std::string o = "\"";
+    for (char c : v) { if (c == '"') o += '"'; o += c; }
+    return o + "\"";
+  };
+  f << q("GRAPH") << ',' << q("Parameters") << ',' << q("Size") << ',' << q("Build time") << ',' << q("Avg degree") << ','
+    << q("Max degree") << '\n';
+  f << q(G.name) << ',' << q(G.params) << ',' << G.size << ',' << G.time << ',' << G.avg_deg << ',' << G.max_deg << '\n' << '\n';
+  const char* cols[] = {"Num queries", "Target recall", "Actual recall", "QPS", "Average Cmps", "Tail Cmps", "Average Visited",
+                        "Tail Visited", "k", "Q", "cut"};
+  for (size_t i = 0; i < 11; i++) f << (i ? "," : "") << q(cols[i]);
+  f << '\n';
+  for (size_t i = 0; i < results.size(); i++) {
+    const nn_result& N = results[i];
+    f << N.num_queries << ',' << buckets[i] << ',' << N.recall << ',' << (float)N.QPS << ',' << N.avg_cmps << ',' << N.tail_cmps << ','
+      << N.avg_visited << ',' << N.tail_visited << ',' << N.k << ',' << N.beamQ << ',' << (float)N.cut << '\n';
+  }
+  f << '\n' << '\n';
+}
+
 // search_and_parse (check_nn_recall.h:181-268).  `check(QP)` runs one checkRecall (plain or quantised + rerank).
 template <class Check>
-std::vector<nn_result> search_and_parse(Check&& check, size_t n, long max_degree, long k, long fixed_beam_width, int rerank_factor = 100) {
+std::vector<nn_result> search_and_parse(Check&& check, size_t n, long max_degree, long k, long fixed_beam_width, int rerank_factor = 100,
+                                        const char* res_file = nullptr, const Graph_* G_ = nullptr) {
   std::vector<nn_result> results;
   const long r = k == 0 ? 10 : k;                                                          // :220-221
   QueryParams QP(r, r, 1.35, (long)n, max_degree);
@@ -130,8 +168,9 @@ std::vector<nn_result> search_and_parse(Check&& check, size_t n, long max_degree
   }
   const std::vector<float> buckets = {.1f, .2f, .3f, .4f, .5f, .6f, .7f, .75f, .8f, .85f, .9f, .93f, .95f, .97f, .98f, .99f, .995f,
                                       .999f, .9995f, .9999f, .99995f, .99999f};
-  parse_result(results, buckets);
+  auto [best, kept] = parse_result(results, buckets);
   std::cout << std::endl;
+  if (res_file != nullptr && G_ != nullptr) write_to_csv(std::string(res_file), kept, best, *G_);       // :265-266
   return results;
 }
 

@@ -6,6 +6,7 @@
 // -self 1 -range 1 -radius -radius_2 [-use_existing 1]  (vamana/neighbors.h:86-104)
 // -quantize_bits 8 with -data_type float  (neighborsTime.C:157-164,190-197)
 // -quantize_mode 1 [-rerank_factor 100] with -data_type float  (vamana/neighbors.h:117-147)
+// -res_path <csv> (sweep mode: one row per recall bucket, check_nn_recall.h:127-158)
 // -two_pass 1 (= -num_passes 2), -normalize 1 (float data)  (neighborsTime.C:104-106,113,147-153)
 #include <cstring>
 #include <map>
@@ -120,6 +121,7 @@ int run_on(const Args& a, PointRange<Point>& Points, PointRange<Point>* QueriesI
   if (alg == "hcnng") BP = BuildParams(a.num("-num_clusters", 30), a.num("-cluster_size", 1000), a.num("-mst_deg", 3));
   else BP = BuildParams(a.num("-R", 64), a.num("-L", 128), a.flt("-alpha", 1.2), (int)(a.num("-two_pass", 0) == 1 ? 2 : a.num("-num_passes", 1)));
   Graph<indexType> G;
+  double build_time = 0;
   if (a.str("-graph_path")) {
     G = Graph<indexType>(a.str("-graph_path"));
   } else {
@@ -135,7 +137,8 @@ int run_on(const Args& a, PointRange<Point>& Points, PointRange<Point>* QueriesI
       stats<indexType> BuildStats(Points.size());
       I.build_index(G, Points, BuildStats);
     }
-    std::cout << "ANN: " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << std::endl;
+    build_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::cout << "ANN: " << build_time << std::endl;
     if (a.str("-graph_outfile")) G.save(a.str("-graph_outfile"));
   }
   size_t tot = 0, mx = 0;
@@ -146,8 +149,13 @@ int run_on(const Args& a, PointRange<Point>& Points, PointRange<Point>* QueriesI
     groundTruth<indexType> GT(a.str("-gt_path"));
     DeviceIndex<PR, indexType> DI(Points, &G, 0, (int)a.num("-device", 0));
     // -Q given: five repetitions at that beam (:224-229); otherwise the reference's sweep + recall-bucket table
+    Graph_ G_;                                                    // vamana/neighbors.h:65-73, HCNNG/neighbors.h
+    G_.name = alg == "hcnng" ? "HCNNG" : "Vamana";
+    G_.params = alg == "hcnng" ? "Trees = " + std::to_string(BP.num_clusters) : "R = " + std::to_string(BP.R) + ", L = " + std::to_string(BP.L);
+    G_.size = (long)G.size(); G_.avg_deg = (double)tot / G.size(); G_.max_deg = (int)mx; G_.time = build_time;
+    G_.print();
     search_and_parse([&](const QueryParams& QP) { return checkRecall<PR, indexType>(DI, Queries, GT, 0, k == 0 ? 10 : k, QP, Q != 0 || a.num("-verbose", 0)); },
-                     G.size(), (long)G.max_degree(), k, Q);
+                     G.size(), (long)G.max_degree(), k, Q, 100, a.str("-res_path"), &G_);
   } else if (a.num("-self", 0) && a.num("-range", 0)) {
     // vamana/neighbors.h:86-104: every base point range-searches from its own vertex.  same_as() skips that
     // start, so upstream reports 0 edges here; `-use_existing 1` seeds with the point's out-neighbours instead

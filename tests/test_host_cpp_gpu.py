@@ -193,6 +193,18 @@ def test_cli_default_is_the_reference_sweep(exe, files, oracle):
     assert len(table) >= 3
     recs = [float(t[0]) for t in table]
     assert recs == sorted(recs)                      # one best-QPS line per bucket, buckets ascending
+    # -res_path: the same table as a CSV report (check_nn_recall.h:127-158), appended per run
+    csvp = d / "res.csv"
+    outs = [_run(exe, "-base_path", d / "base.bin", "-query_path", d / "query.bin", "-gt_path", d / "gt.ibin", "-graph_path",
+                 d / "s.graph", "-data_type", "uint8", "-k", 10, "-res_path", csvp) for _ in range(2)]
+    nlines = sum(len(re.findall(r"For 10@10 recall", o)) for o in outs)
+    rows = open(csvp).read().split("\n")
+    assert rows[0] == '"GRAPH","Parameters","Size","Build time","Avg degree","Max degree"'
+    assert rows[1].startswith('"Vamana","R = 64, L = 128",8000,') and rows[2] == ""
+    assert rows[3].startswith('"Num queries","Target recall","Actual recall","QPS"')
+    data = [r for r in rows[4:] if r and not r.startswith('"')]
+    assert len(data) == nlines and all(len(r.split(",")) == 11 for r in data)
+    assert sum(1 for r in rows if r.startswith('"GRAPH"')) == 2
 
 
 def test_compute_groundtruth_cli(exe, files, oracle):
