@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define PANN_ABI_VERSION 1
+#define PANN_ABI_VERSION 2
 
 /* status codes */
 #define PANN_OK 0
@@ -84,7 +84,17 @@ typedef struct pann_search_out {
   uint32_t* visited_ids;   /* nq x visited_cap */
   float* visited_dists;    /* nq x visited_cap */
   uint32_t visited_cap;
+  uint32_t* status;        /* 1 word, optional: PANN_STATUS_* bits of this launch.  pann_batch_search_dev copies the
+                              kernel's status word here on the launch stream (device pointer; read it after the stream
+                              has been synchronised); the host entry points write it before returning. */
 } pann_search_out;
+
+/* bits of pann_search_out::status */
+#define PANN_STATUS_VISITED_OVERFLOW 1u /* a visited list was longer than visited_cap: the lists are truncated */
+#define PANN_STATUS_DROPPED_OVERFLOW 2u /* the per-query "dropped" scratch (equivalence 2) was too small:
+                                           results of this launch are NOT valid.  The host entry points grow the scratch
+                                           and run the batch again by themselves; after a _dev launch that reports it,
+                                           call pann_index_reserve_dropped() with a larger capacity and launch again. */
 
 typedef struct pann_index pann_index;
 
@@ -114,7 +124,15 @@ int pann_index_device(const pann_index* idx);
  * the CPU path (one lane per candidate: several times slower).  No effect on integer types. */
 int pann_index_set_exact_float_order(pann_index* idx, int on);
 
-/* Replace the whole graph from a host n x (max_deg+1) slab. */
+/* Capacity (entries per query) of the scratch list that remembers visited vertices which the cut-prune
+ * (beamSearch.h:190-195) dropped from a frontier that is not yet full; default 256.  Only searches with k > 0 on a
+ * metric index that visit more than `cap` vertices before the frontier fills can exceed it (e.g. cut = 1.0 on a
+ * path-like graph).  Never shrinks. */
+int pann_index_reserve_dropped(pann_index* idx, uint32_t cap);
+uint32_t pann_index_dropped_capacity(const pann_index* idx);
+
+/* Replace the whole graph from a host n x (max_deg+1) slab.  Neighbour ids >= n are rejected with
+ * PANN_ERR_BAD_ARG (the offending rows are left empty): the kernels gather points[id] unchecked. */
 int pann_index_set_graph(pann_index* idx, const uint32_t* graph);
 /* Replace m rows: rows is m x (max_deg+1) in the reference layout (edgeRange::update_neighbors,
  * graph.h:84-99).  Must not overlap a search on the same handle (vamana/index.h:247-270). */

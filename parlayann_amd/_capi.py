@@ -23,6 +23,8 @@ PANN_U8, PANN_I8, PANN_F32, PANN_F16 = 0, 1, 2, 3
 PANN_L2, PANN_MIPS = 0, 1
 PANN_OK = 0
 PANN_ERR_OVERFLOW = 5
+PANN_ABI_VERSION = 2
+PANN_STATUS_VISITED_OVERFLOW, PANN_STATUS_DROPPED_OVERFLOW = 1, 2
 
 u32p = C.POINTER(C.c_uint32)
 u64p = C.POINTER(C.c_uint64)
@@ -40,7 +42,7 @@ class SearchOut(C.Structure):
                 ("frontier_size", C.c_void_p), ("visited_count", C.c_void_p),
                 ("dist_cmps", C.c_void_p), ("degree_sum", C.c_void_p),
                 ("visited_ids", C.c_void_p), ("visited_dists", C.c_void_p),
-                ("visited_cap", C.c_uint32)]
+                ("visited_cap", C.c_uint32), ("status", C.c_void_p)]
 
 
 class BuildStats(C.Structure):
@@ -64,6 +66,8 @@ SIGNATURES = {
     "pann_index_set_exact_float_order": (C.c_int, [C.c_void_p, C.c_int]),
     "pann_range_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32,
                                     C.c_int, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pann_index_reserve_dropped": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "pann_index_dropped_capacity": (C.c_uint32, [C.c_void_p]),
     "pann_index_set_graph": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pann_index_update_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "pann_index_get_graph": (C.c_int, [C.c_void_p, C.c_void_p]),

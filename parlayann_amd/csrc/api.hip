@@ -68,6 +68,7 @@ struct pann_index {
   hipStream_t stream = nullptr;
   Workspace ws, ws2, ws3;   // kernel scratch (search / prune / re-prune)
   uint32_t vcap = 0;        // visited-list capacity used by the builder (grows on overflow)
+  uint32_t dcap = 256;      // dropped-list capacity of the searches (pann_index_reserve_dropped; grows on overflow)
   DevBuf stage[12];      // staging for host-pointer calls
   PinnedBuf pin_in, pin_out;   // packed pinned staging of pann_batch_search
 };
@@ -89,16 +90,24 @@ struct DeviceGuard {
 };
 
 // reference layout n x (max_deg+1), slot 0 = degree  ->  device layout n x gstride, SENTINEL padded
+// A neighbour id >= n would be gathered unchecked by every kernel (points + id * pstride): such a row is left empty
+// and *bad is raised, the host then returns PANN_ERR_BAD_ARG (a graph file of another dataset, a truncated file).
 __global__ void graph_to_device_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
                                        uint64_t nrows, uint32_t max_deg, uint32_t gstride,
-                                       const uint32_t* __restrict__ row_ids) {
+                                       const uint32_t* __restrict__ row_ids, uint64_t n, uint32_t* __restrict__ bad) {
   const uint64_t r = blockIdx.x;
   if (r >= nrows) return;
   const uint32_t* s = src + r * (uint64_t)(max_deg + 1);
   const uint64_t target = row_ids ? row_ids[r] : r;
   uint32_t* d = dst + target * (uint64_t)gstride;
   const uint32_t deg = min(s[0], max_deg);
-  for (uint32_t i = threadIdx.x; i < gstride; i += blockDim.x) d[i] = (i < deg) ? s[1 + i] : SENTINEL;
+  bool ok = true;                                      // one wave per row
+  for (uint32_t i0 = 0; i0 < deg; i0 += 64) {
+    const uint32_t i = i0 + threadIdx.x;
+    ok = ok && (__ballot(i < deg && (uint64_t)s[1 + i] >= n) == 0ull);
+  }
+  if (!ok && threadIdx.x == 0) atomicOr(bad, 1u);
+  for (uint32_t i = threadIdx.x; i < gstride; i += blockDim.x) d[i] = (ok && i < deg) ? s[1 + i] : SENTINEL;
 }
 
 __global__ void graph_to_host_layout_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
@@ -135,6 +144,8 @@ int upload_graph_rows(pann_index* idx, const uint32_t* h_rows, uint64_t m, const
   const size_t row_bytes = (size_t)(ix.max_deg + 1) * 4;
   // stream in slices so the staging buffer stays bounded (288 GB HBM, but host slabs can be huge)
   const uint64_t slice = std::max<uint64_t>(1, (256ull << 20) / row_bytes);
+  if (int rc = idx->stage[9].ensure(4)) return rc;
+  PANN_HIP(hipMemsetAsync(idx->stage[9].p, 0, 4, idx->stream));
   for (uint64_t r0 = 0; r0 < m; r0 += slice) {
     const uint64_t cnt = std::min(slice, m - r0);
     int rc = idx->stage[0].ensure(cnt * row_bytes); if (rc) return rc;
@@ -147,10 +158,13 @@ int upload_graph_rows(pann_index* idx, const uint32_t* h_rows, uint64_t m, const
     }
     uint32_t* dst = h_row_ids ? ix.graph : ix.graph + r0 * (uint64_t)ix.gstride;
     hipLaunchKernelGGL(graph_to_device_kernel, dim3((uint32_t)cnt), dim3(64), 0, idx->stream,
-                       idx->stage[0].as<uint32_t>(), dst, cnt, ix.max_deg, ix.gstride, d_ids);
+                       idx->stage[0].as<uint32_t>(), dst, cnt, ix.max_deg, ix.gstride, d_ids, ix.n, idx->stage[9].as<uint32_t>());
     PANN_HIP(hipGetLastError());
     PANN_HIP(hipStreamSynchronize(idx->stream));
   }
+  uint32_t bad = 0;
+  PANN_HIP(hipMemcpy(&bad, idx->stage[9].p, 4, hipMemcpyDeviceToHost));
+  if (bad) { set_error("graph upload: neighbour id out of range (>= number of points); those rows were left empty"); return PANN_ERR_BAD_ARG; }
   return PANN_OK;
 }
 
@@ -245,6 +259,14 @@ int pann_index_set_exact_float_order(pann_index* idx, int on) {
   return PANN_OK;
 }
 
+int pann_index_reserve_dropped(pann_index* idx, uint32_t cap) {
+  if (int rc = check_idx(idx, "pann_index_reserve_dropped")) return rc;
+  if (cap > (1u << 30)) { set_error("pann_index_reserve_dropped: capacity out of range"); return PANN_ERR_BAD_ARG; }
+  if (cap > idx->dcap) idx->dcap = (cap + 63) / 64 * 64;
+  return PANN_OK;
+}
+uint32_t pann_index_dropped_capacity(const pann_index* idx) { return idx ? idx->dcap : 0; }
+
 int pann_index_set_graph(pann_index* idx, const uint32_t* graph) {
   if (int rc = check_idx(idx, "pann_index_set_graph")) return rc;
   if (!graph) { set_error("pann_index_set_graph: null graph"); return PANN_ERR_BAD_ARG; }
@@ -307,6 +329,7 @@ int pann_batch_search_dev(pann_index* idx, const void* d_queries, const uint32_t
   a.queries = (const uint8_t*)d_queries; a.qstride = q_stride_bytes; a.query_ids = d_query_ids;
   a.nq = nq; a.starts = d_starts; a.nstarts = nstarts;
   a.k = qp->k; a.beam = qp->beam; a.limit = qp->limit; a.degree_limit = qp->degree_limit; a.cut = qp->cut;
+  a.dcap = idx->dcap;
   a.out = *d_out;
   if (int rc = idx->ws.ensure(search_workspace_bytes(idx->ix, a))) return rc;
   return launch_beam_search(idx->ix, a, idx->ws.buf, idx->ws.bytes, (hipStream_t)stream);
@@ -361,26 +384,32 @@ static int batch_search_host(pann_index* idx, const void* queries, const uint32_
   d.visited_ids = (uint32_t*)dptr(6); d.visited_dists = (float*)dptr(7);
   if (!d.visited_ids && !d.visited_dists) d.visited_cap = 0;
 
-  int rc;
-  {
+  d.status = nullptr;   // read from the workspace below
+  uint32_t status = 0;
+  for (;;) {
     SearchArgs a;
     a.queries = (const uint8_t*)d_q; a.qstride = q_stride_bytes; a.query_ids = d_qid;
     a.nq = nq; a.starts = d_starts; a.nstarts = nstarts; a.starts_per_query = per_query;
     a.k = qp->k; a.beam = qp->beam; a.limit = qp->limit; a.degree_limit = qp->degree_limit; a.cut = qp->cut;
+    a.dcap = idx->dcap;
     a.out = d;
-    if ((rc = idx->ws.ensure(search_workspace_bytes(idx->ix, a)))) return rc;
-    rc = launch_beam_search(idx->ix, a, idx->ws.buf, idx->ws.bytes, st);
+    if (int rc = idx->ws.ensure(search_workspace_bytes(idx->ix, a))) return rc;
+    if (int rc = launch_beam_search(idx->ix, a, idx->ws.buf, idx->ws.bytes, st)) return rc;
+    // the status word travels with the results
+    PANN_HIP(hipMemcpyAsync((uint8_t*)idx->stage[4].p + out_bytes, (uint8_t*)idx->ws.buf + 64, 4, hipMemcpyDeviceToDevice, st));
+    PANN_HIP(hipMemcpyAsync(idx->pin_out.p, idx->stage[4].p, out_bytes + 4, hipMemcpyDeviceToHost, st));
+    PANN_HIP(hipStreamSynchronize(st));
+    std::memcpy(&status, (uint8_t*)idx->pin_out.p + out_bytes, 4);
+    if (!(status & PANN_STATUS_DROPPED_OVERFLOW)) break;
+    // The reference has no such list (its `visited` vector grows as needed, beamSearch.h:80,113): grow ours and run
+    // the batch again.  A query can drop at most one entry per visited vertex, so min(limit, n) entries always suffice.
+    const uint64_t need = (uint64_t)std::min<int64_t>(std::max<int64_t>(qp->limit, 1), (int64_t)ix.n);
+    if ((uint64_t)idx->dcap >= need) { set_error("pann_batch_search: internal dropped-list overflow"); return PANN_ERR_OVERFLOW; }
+    idx->dcap = (uint32_t)std::min<uint64_t>((uint64_t)idx->dcap * 8, (need + 63) / 64 * 64);
   }
-  if (rc) return rc;
-  // the status word travels with the results
-  PANN_HIP(hipMemcpyAsync((uint8_t*)idx->stage[4].p + out_bytes, (uint8_t*)idx->ws.buf + 64, 4, hipMemcpyDeviceToDevice, st));
-  PANN_HIP(hipMemcpyAsync(idx->pin_out.p, idx->stage[4].p, out_bytes + 4, hipMemcpyDeviceToHost, st));
-  PANN_HIP(hipStreamSynchronize(st));
   for (auto& x : pc) if (x.bytes) std::memcpy(x.host, (uint8_t*)idx->pin_out.p + x.off, x.bytes);
-  uint32_t status = 0;
-  std::memcpy(&status, (uint8_t*)idx->pin_out.p + out_bytes, 4);
-  if (status & 1u) { set_error("pann_batch_search: visited list longer than visited_cap"); return PANN_ERR_OVERFLOW; }
-  if (status & 2u) { set_error("pann_batch_search: internal dropped-list overflow"); return PANN_ERR_OVERFLOW; }
+  if (out->status) *out->status = status;
+  if (status & PANN_STATUS_VISITED_OVERFLOW) { set_error("pann_batch_search: visited list longer than visited_cap"); return PANN_ERR_OVERFLOW; }
   return PANN_OK;
 }
 

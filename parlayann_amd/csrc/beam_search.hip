@@ -966,7 +966,7 @@ static Plan make_plan(const DeviceIndex& ix, const SearchArgs& a) {
   p.deg_eff = (uint32_t)dl;
   // at merge time |C| <= (beam/8 - 1) + deg_eff (accumulation stops at beam/8); starts first
   p.ccap = (std::max<uint32_t>(beam / 8 + p.deg_eff, a.nstarts) + 63) / 64 * 64;
-  p.dcap = 256;
+  p.dcap = std::max<uint32_t>(a.dcap, 64);
   const bool nch1 = layout_query_in_registers(ix);
   size_t fixed = (size_t)p.bcap * 8 * 2 + (size_t)p.ccap * 8 + (size_t)p.bcap * 2 +
                  (size_t)p.ccap * 2 + (nch1 ? 0 : (size_t)ix.nch * ix.lpc * 16);
@@ -1109,6 +1109,8 @@ int launch_beam_search(const DeviceIndex& ix, const SearchArgs& a, void* ws, siz
   PANN_DISPATCH(PANN_F16, PANN_L2) PANN_DISPATCH(PANN_F16, PANN_MIPS)
 #undef PANN_DISPATCH
   if (e != hipSuccess) return hip_fail(e, "beam_search_kernel launch");
+  // the status word follows the results on the launch stream (pann_search_out::status, device pointer here)
+  if (a.out.status) PANN_HIP(hipMemcpyAsync(a.out.status, P.status, 4, hipMemcpyDeviceToDevice, stream));
 #ifdef PANN_STAMPS
   if (getenv("PANN_STAMPS_PRINT") && a.nq >= 1000) {
     (void)hipStreamSynchronize(stream);

@@ -45,6 +45,7 @@ struct SearchArgs {  // one batched beam search, everything device resident
   const uint32_t* starts; uint32_t nstarts;
   int starts_per_query = 0;                  // starts is nq x nstarts (beamSearchRandom)
   int64_t k, beam, limit, degree_limit; double cut;
+  uint32_t dcap = 256;                       // dropped-list entries per query (pann_index_reserve_dropped)
   pann_search_out out;
 };
 

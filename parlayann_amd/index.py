@@ -78,6 +78,22 @@ class DeviceIndex:
     def handle(self):
         return self._h
 
+    def _queries(self, queries):
+        """external query rows: C-contiguous nq x d of the INDEX dtype (a float32 array handed to an f16 index would be
+        reinterpreted byte-wise by the C-ABI, which only sees a pointer and a stride)"""
+        q = np.ascontiguousarray(queries)
+        if q.dtype != self.dtype or q.ndim != 2 or q.shape[1] != self.d:
+            raise ValueError(f"queries must be nq x {self.d} of dtype {self.dtype}, got {q.shape} {q.dtype}")
+        return q
+
+    def reserve_dropped(self, cap):
+        """pann_index_reserve_dropped: per-query scratch of the cut-prune bookkeeping (include/pann.h)"""
+        check(self._lib.pann_index_reserve_dropped(self._h, int(cap)))
+
+    @property
+    def dropped_capacity(self):
+        return int(self._lib.pann_index_dropped_capacity(self._h))
+
     # ---- graph ----
     def set_graph(self, graph):
         graph = np.ascontiguousarray(graph, dtype=np.uint32)
@@ -112,12 +128,13 @@ class DeviceIndex:
             "degree_sum": np.empty(nq, dtype=np.uint32),
             "visited_ids": np.empty((nq, visited_cap), dtype=np.uint32) if visited_cap else None,
             "visited_dists": np.empty((nq, visited_cap), dtype=np.float32) if visited_cap else None,
+            "status": np.zeros(1, dtype=np.uint32),
         }
         out = SearchOut(ids=_ptr(res["ids"]), dists=_ptr(res["dists"]), out_k=out_k,
                         frontier_size=_ptr(res["frontier_size"]), visited_count=_ptr(res["visited_count"]),
                         dist_cmps=_ptr(res["dist_cmps"]), degree_sum=_ptr(res["degree_sum"]),
                         visited_ids=_ptr(res["visited_ids"]), visited_dists=_ptr(res["visited_dists"]),
-                        visited_cap=visited_cap)
+                        visited_cap=visited_cap, status=_ptr(res["status"]))
         starts = np.ascontiguousarray(starts, dtype=np.uint32)
         per_query = starts.ndim == 2          # nq x nstarts: beamSearchRandom-style, one start set per query
         if per_query and starts.shape[0] != nq:
@@ -125,9 +142,7 @@ class DeviceIndex:
         q = qid = None
         stride = 0
         if queries is not None:
-            q = np.ascontiguousarray(queries)
-            if q.dtype != self.dtype or q.ndim != 2 or q.shape[1] != self.d:
-                raise ValueError("queries must be nq x d of the index dtype")
+            q = self._queries(queries)
             stride = _row_stride(q)
         else:
             qid = np.ascontiguousarray(query_ids, dtype=np.uint32)
@@ -176,7 +191,7 @@ class DeviceIndex:
         if (queries is None) == (query_ids is None):
             raise ValueError("exactly one of queries / query_ids must be given")
         if queries is not None:
-            q = np.ascontiguousarray(queries); nq = len(q); qp, qs, qi = _ptr(q), _row_stride(q), None
+            q = self._queries(queries); nq = len(q); qp, qs, qi = _ptr(q), _row_stride(q), None
         else:
             qid = np.ascontiguousarray(query_ids, dtype=np.uint32); nq = len(qid); qp, qs, qi = None, 0, _ptr(qid)
         if per_query and len(starts) != nq:
@@ -196,7 +211,7 @@ class DeviceIndex:
         return out
 
     def query_distances(self, queries, ids):
-        q = np.ascontiguousarray(queries); ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        q = self._queries(queries); ids = np.ascontiguousarray(ids, dtype=np.uint32)
         out = np.empty((len(q), len(ids)), np.float32)
         check(self._lib.pann_query_distances(self._h, _ptr(q), len(q), _row_stride(q), _ptr(ids), len(ids), _ptr(out)))
         return out
@@ -214,7 +229,7 @@ class DeviceIndex:
 
     def bruteforce_knn(self, queries, k):
         """data_tools/compute_groundtruth.cpp:22-59."""
-        q = np.ascontiguousarray(queries)
+        q = self._queries(queries)
         oi = np.empty((len(q), k), np.uint32); od = np.empty((len(q), k), np.float32)
         check(self._lib.pann_bruteforce_knn(self._h, _ptr(q), len(q), _row_stride(q), k, _ptr(oi), _ptr(od)))
         return oi, od
@@ -230,7 +245,7 @@ class DeviceIndex:
 
     def rerank(self, queries, cand_ids, cand_counts, k, resort=True):
         """beamSearch.h:426-452: exact distances of each query's candidates, (re)sorted, first k."""
-        q = np.ascontiguousarray(queries)
+        q = self._queries(queries)
         cand = np.ascontiguousarray(cand_ids, dtype=np.uint32)
         cnt = None if cand_counts is None else np.ascontiguousarray(cand_counts, dtype=np.uint32)
         oi = np.empty((len(q), k), np.uint32); od = np.empty((len(q), k), np.float32)

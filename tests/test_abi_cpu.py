@@ -25,14 +25,14 @@ def test_header_symbols_are_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/pann.h but not exported by libpann.so"
     assert sorted(_capi.SIGNATURES) == names
-    assert _capi.load().pann_abi_version() == 1
+    assert _capi.load().pann_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
     from parlayann_amd import _capi
     assert C.sizeof(_capi.QueryParams) == 48          # 4x int64/double + int64 + int32 + float
     assert _capi.QueryParams.limit.offset == 24 and _capi.QueryParams.rerank_factor.offset == 40
-    assert C.sizeof(_capi.SearchOut) == 80
+    assert C.sizeof(_capi.SearchOut) == 88
     assert C.sizeof(_capi.BuildStats) == 56
 
 

@@ -185,3 +185,107 @@ def test_rows_of_64_bytes_use_the_lds_query_variants(oracle):
         cols = np.arange(24)[None, :]
         np.testing.assert_array_equal(np.where(cols < G[:, :1], G[:, 1:], 0), np.where(cols < Gd[:, :1], Gd[:, 1:], 0))
         iz.close()
+
+
+def _line_graph(n):
+    """points on a line (x_i = i), vertex i linked to i+-1, i+-2: a greedy walk from 0 to a far query visits ~n/2
+    vertices while cut = 1.0, k = 1 keeps the frontier at two or three entries, i.e. never full"""
+    X = np.zeros((n, 8), np.float32)
+    X[:, 0] = np.arange(n)
+    G = np.zeros((n, 5), np.uint32)
+    for i in range(n):
+        nb = [j for j in (i - 2, i - 1, i + 1, i + 2) if 0 <= j < n]
+        G[i, 0] = len(nb); G[i, 1:1 + len(nb)] = nb
+    return X, G
+
+
+@pytest.mark.parametrize("beam", [16, 100, 300])       # register-frontier (b64, b128) and LDS-frontier kernels
+def test_dropped_list_grows_instead_of_failing(oracle, beam):
+    """More than 256 visited vertices cut from a frontier that never fills (`ndrop` near `dcap` was
+    untested and an overflow was a hard error where the reference simply succeeds)."""
+    X, G = _line_graph(1500)
+    Q = np.zeros((3, 8), np.float32); Q[:, 0] = [1499.0, 1400.5, 700.0]
+    o = oracle.batch_search(X, G, queries=Q, k=1, beam=beam, cut=1.0, out_k=2)
+    assert o["visited_count"].max() > 600
+    ix = DeviceIndex(X, G)
+    assert ix.dropped_capacity == 256
+    g = ix.batch_search(Q, k=1, beam=beam, cut=1.0, out_k=2)
+    _cmp(o, g)
+    assert ix.dropped_capacity > 256 and g["status"][0] == 0
+    ix.close()
+
+
+def test_dev_entry_reports_dropped_overflow_in_status_word(oracle):
+    """pann_batch_search_dev performs no synchronisation: the status word is copied to pann_search_out::status on the
+    launch stream; bit 2 = results invalid, reserve a larger list and launch again"""
+    import ctypes as C
+    import torch
+    from parlayann_amd import _capi
+    from parlayann_amd._capi import QueryParams, SearchOut, check
+    X, G = _line_graph(1500)
+    Q = np.zeros((2, 8), np.float32); Q[:, 0] = [1499.0, 3.0]
+    o = oracle.batch_search(X, G, queries=Q, k=1, beam=16, cut=1.0, out_k=2)
+    ix = DeviceIndex(X, G)
+    lib = _capi.load()
+    dev = torch.device("cuda", 0)
+    d_q = torch.from_numpy(Q.view(np.uint8).reshape(2, -1)).to(dev)
+    d_s = torch.zeros(1, dtype=torch.int32, device=dev)
+    d_ids = torch.empty((2, 2), dtype=torch.int32, device=dev)
+    d_dists = torch.empty((2, 2), dtype=torch.float32, device=dev)
+    d_vis = torch.empty(2, dtype=torch.int32, device=dev)
+    d_status = torch.full((1,), 77, dtype=torch.int32, device=dev)
+    qp = QueryParams(k=1, beam=16, cut=1.0, limit=1500, degree_limit=4, rerank_factor=100, pad=1.0)
+    out = SearchOut(ids=d_ids.data_ptr(), dists=d_dists.data_ptr(), out_k=2, visited_count=d_vis.data_ptr(),
+                    status=d_status.data_ptr())
+    st = torch.cuda.current_stream(dev)
+
+    def launch():
+        check(lib.pann_batch_search_dev(ix.handle, d_q.data_ptr(), None, 2, 32, d_s.data_ptr(), 1, C.byref(qp), C.byref(out),
+                                        C.c_void_p(st.cuda_stream)))
+        torch.cuda.synchronize(dev)
+        return int(d_status.item())
+    assert launch() & _capi.PANN_STATUS_DROPPED_OVERFLOW
+    ix.reserve_dropped(1500)
+    assert launch() == 0
+    np.testing.assert_array_equal(d_ids.cpu().numpy().view(np.uint32), o["ids"])
+    np.testing.assert_array_equal(d_dists.cpu().numpy(), o["dists"])
+    np.testing.assert_array_equal(d_vis.cpu().numpy().view(np.uint32), o["visited_count"])
+    ix.close()
+
+
+def test_graph_upload_rejects_out_of_range_neighbours():
+    """a graph file of another dataset must be PANN_ERR_BAD_ARG, not an out-of-bounds gather"""
+    from parlayann_amd import PannError
+    X = datasets.sift_like(200, 16, seed=1, dtype=np.uint8)
+    G = np.zeros((200, 9), np.uint32)
+    G[:, 0] = 2; G[:, 1] = (np.arange(200) + 1) % 200; G[:, 2] = (np.arange(200) + 7) % 200
+    bad = G.copy(); bad[17, 2] = 200                       # == n: out of range
+    with pytest.raises(PannError) as e:
+        DeviceIndex(X, bad)
+    assert e.value.code == 1 and "out of range" in str(e.value)
+    ix = DeviceIndex(X, G)
+    with pytest.raises(PannError):
+        ix.set_graph(bad)
+    with pytest.raises(PannError):
+        ix.update_rows(np.array([5], np.uint32), np.array([[1, 4000000000, 0, 0, 0, 0, 0, 0, 0]], np.uint32))
+    # the offending rows are left empty, the rest of the upload stands: searches stay in bounds
+    g = ix.batch_search(X[:4], k=1, beam=8)
+    assert g["ids"].max() < 200
+    ix.set_graph(G)
+    ix.close()
+
+
+def test_query_dtype_and_width_are_checked_everywhere():
+    X = datasets.sift_like(300, 16, seed=1, dtype=np.float16)
+    ix = DeviceIndex(X, max_degree=8)
+    ix.vamana_build(8, 16, 1.2)
+    wrong = X[:4].astype(np.float32)
+    for call in (lambda q: ix.batch_search(q, k=1, beam=8), lambda q: ix.bruteforce_knn(q, 3),
+                 lambda q: ix.query_distances(q, [0, 1]), lambda q: ix.rerank(q, np.zeros((len(q), 4), np.uint32), None, 2),
+                 lambda q: ix.range_search([0], 10.0, 8, queries=q)):
+        with pytest.raises(ValueError):
+            call(wrong)
+        with pytest.raises(ValueError):
+            call(X[:4, :8])
+        call(X[:4])
+    ix.close()
