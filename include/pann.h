@@ -200,6 +200,11 @@ int pann_robust_prune_batch(pann_index* idx, const uint32_t* owners, uint64_t m,
 typedef struct pann_build_stats {
   double t_search_s, t_prune_s, t_bidirect_s, t_reprune_s; /* the reference's three phase timers, :217-222 */
   uint64_t search_dist_cmps, prune_dist_cmps, visited_total;
+  /* optional host arrays of n entries each (NULL: skipped), ACCUMULATED like the reference's BuildStats
+   * (stats.h:63-73): per inserted point its |visited| (vamana/index.h:262) and its beam-search + robustPrune
+   * comparisons (:261,266); a re-pruned reverse-edge target gets that prune's comparisons (:298) */
+  uint32_t* per_point_visited;
+  uint32_t* per_point_dist_cmps;
 } pann_build_stats;
 
 /* One batch: for every id in batch_ids (m of them) beam-search from `start` with

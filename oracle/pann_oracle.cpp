@@ -392,6 +392,13 @@ void pann_oracle_permutation(uint64_t m, uint64_t seed, uint32_t* out) {
   }
 }
 
+// BuildStats of the reference (stats.h:63-73), per point: visited += |visited| (vamana/index.h:262), distances +=
+// beam-search + robustPrune comparisons (:261,266) and, for a re-pruned reverse-edge target, that prune's (:298).
+// Optional: the arrays (n entries, accumulated) are registered before a build / insert call.
+static uint32_t* g_pp_visited = nullptr;
+static uint32_t* g_pp_dists = nullptr;
+void pann_oracle_set_build_point_stats(uint32_t* visited, uint32_t* dists) { g_pp_visited = visited; g_pp_dists = dists; }
+
 // One batch of vamana/index.h:188-316 (steps 1-4) on a HOST graph in the reference layout.
 // stats6: [search_dist_cmps, prune_dist_cmps, visited_total, t_search_us, t_prune_us, t_bidirect_us]
 int pann_oracle_vamana_insert_batch(const void* points, uint64_t n, uint32_t d, int dtype,
@@ -413,6 +420,8 @@ int pann_oracle_vamana_insert_batch(const void* points, uint64_t n, uint32_t d, 
     std::vector<IdDist> cand = Rs.visited;
     robust_prune(D, p, cand, alpha, R, true, new_out[i], &dc);
     pdc += dc;
+    if (g_pp_visited) g_pp_visited[p] += (uint32_t)Rs.visited.size();     // one writer per p within a batch
+    if (g_pp_dists) g_pp_dists[p] += (uint32_t)(Rs.dist_cmps + dc);
   });
   auto t1 = std::chrono::steady_clock::now();
   const uint64_t rs = (uint64_t)maxdeg + 1;
@@ -451,6 +460,7 @@ int pann_oracle_vamana_insert_batch(const void* points, uint64_t n, uint32_t d, 
       std::vector<uint32_t> out;
       robust_prune(D, v, cand, alpha, R, true, out, &dc);
       pdc += dc;
+      if (g_pp_dists) g_pp_dists[v] += (uint32_t)dc;                        // one group per target v
       row[0] = (uint32_t)out.size();
       for (size_t j = 0; j < out.size(); j++) row[1 + j] = out[j];
     }

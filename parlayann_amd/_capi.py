@@ -48,7 +48,8 @@ class SearchOut(C.Structure):
 class BuildStats(C.Structure):
     _fields_ = [("t_search_s", C.c_double), ("t_prune_s", C.c_double), ("t_bidirect_s", C.c_double),
                 ("t_reprune_s", C.c_double), ("search_dist_cmps", C.c_uint64),
-                ("prune_dist_cmps", C.c_uint64), ("visited_total", C.c_uint64)]
+                ("prune_dist_cmps", C.c_uint64), ("visited_total", C.c_uint64),
+                ("per_point_visited", C.c_void_p), ("per_point_dist_cmps", C.c_void_p)]
 
 
 # every symbol include/pann.h declares: (restype, argtypes)

@@ -738,10 +738,12 @@ int insert_batch_dev(const DeviceIndex& ix, Workspace& ws, Workspace& ws2, Works
       gb.dcmps = h_ddc; gb.m = nheavy;
       if (int rc = run_prune(ix, pb, gb, hk_a, hk_b, (uint32_t)tk, h_tmp, stmp2, st, max_len)) return rc;
       if (stats) {
-        std::vector<uint32_t> hd(nheavy);
+        std::vector<uint32_t> hd(nheavy), ho(stats->per_point_dist_cmps ? nheavy : 0);
         PANN_HIP(hipMemcpyAsync(hd.data(), h_ddc, (size_t)nheavy * 4, hipMemcpyDeviceToHost, st));
+        if (!ho.empty()) PANN_HIP(hipMemcpyAsync(ho.data(), d_hown, (size_t)nheavy * 4, hipMemcpyDeviceToHost, st));
         PANN_HIP(hipStreamSynchronize(st));
         for (uint32_t v : hd) reprune_dc += v;
+        for (size_t i = 0; i < ho.size(); i++) stats->per_point_dist_cmps[ho[i]] += hd[i];      // vamana/index.h:298
       }
     }
     PANN_HIP(hipStreamSynchronize(st));
@@ -752,6 +754,14 @@ int insert_batch_dev(const DeviceIndex& ix, Workspace& ws, Workspace& ws2, Works
       PANN_HIP(hipMemcpy(hp.data(), d_dc, (size_t)m * 4, hipMemcpyDeviceToHost));
       PANN_HIP(hipMemcpy(hv.data(), d_vis_cnt, (size_t)m * 4, hipMemcpyDeviceToHost));
       for (uint32_t i = 0; i < m; i++) { stats->search_dist_cmps += hs[i]; stats->prune_dist_cmps += hp[i]; stats->visited_total += hv[i]; }
+      if (stats->per_point_visited || stats->per_point_dist_cmps) {                                // vamana/index.h:261-266
+        std::vector<uint32_t> hb(m);
+        PANN_HIP(hipMemcpy(hb.data(), d_batch, (size_t)m * 4, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < m; i++) {
+          if (stats->per_point_visited) stats->per_point_visited[hb[i]] += hv[i];
+          if (stats->per_point_dist_cmps) stats->per_point_dist_cmps[hb[i]] += hs[i] + hp[i];
+        }
+      }
       stats->prune_dist_cmps += reprune_dc;
       stats->t_search_s += secs(t0, t1); stats->t_prune_s += secs(t1, t2);
       stats->t_bidirect_s += secs(t2, t3); stats->t_reprune_s += secs(t3, t4);

@@ -1,23 +1,15 @@
-// device_index.h -- RAII owner of a pann_index: the device mirror of (PointRange, Graph).
-// The reference's free functions take (G, Points) by reference and run on the CPU; here the batched
-// entry points take the DeviceIndex that bundles their device copies.  Errors follow the
+// device_index.h -- RAII owner of a pann_index: an EXPLICIT device mirror of (PointRange, Graph), for callers that
+// want to manage the device copy themselves.  The functions with the reference's own argument lists
+// (beam_search(p, G, Points, ...), qsearchAll(...), knn_index::build_index(G, Points, ...)) find their mirror
+// through device_mirror.h instead; both forms end in the same C-ABI calls.  Errors follow the
 // reference's convention: print and abort() (beamSearch.h:38-41,368-372; graph.h:56-58).
 #pragma once
 #include <cstdlib>
 #include <iostream>
 
-#include "../../include/pann.h"
-#include "graph.h"
-#include "point_range.h"
+#include "device_mirror.h"
 
 namespace parlayANN {
-
-inline void pann_check(int rc) {
-  if (rc != PANN_OK) {
-    std::cout << pann_last_error() << std::endl;
-    abort();
-  }
-}
 
 template <class PointRange, typename indexType = unsigned int>
 struct DeviceIndex {

@@ -4,6 +4,7 @@
 // repo: one zero-initialised slab, C stdio for the files, a single bounds/abort helper.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -30,7 +31,8 @@ inline size_t round_up_2mb(size_t bytes) {
 template <typename indexType>
 struct edgeRange {
   edgeRange() = default;
-  edgeRange(indexType* first, indexType* last, indexType owner) : row_(first), cap_(last - first - 1), owner_(owner) {}
+  edgeRange(indexType* first, indexType* last, indexType owner, std::atomic<uint64_t>* version = nullptr)
+      : row_(first), cap_(last - first - 1), owner_(owner), version_(version) {}
 
   size_t size() const { return row_[0]; }
   indexType id() const { return owner_; }
@@ -43,6 +45,7 @@ struct edgeRange {
   void append_neighbor(indexType nbh) {
     if ((long)row_[0] == cap_) graph_detail::die("ERROR in append_neighbor: cannot exceed max degree ", cap_);
     row_[++row_[0]] = nbh;
+    dirty();
   }
 
   template <typename rangeType>
@@ -52,6 +55,7 @@ struct edgeRange {
     indexType* out = row_ + 1 + row_[0];
     for (size_t i = 0; i < r.size(); i++) out[i] = r[i];
     row_[0] += (indexType)r.size();
+    dirty();
   }
 
   template <typename rangeType>
@@ -59,20 +63,25 @@ struct edgeRange {
     if ((long)r.size() > cap_) graph_detail::die("ERROR in update_neighbors: cannot exceed max degree ", cap_);
     for (size_t i = 0; i < r.size(); i++) row_[1 + i] = r[i];
     row_[0] = (indexType)r.size();
+    dirty();
   }
 
-  void clear_neighbors() { row_[0] = 0; }
+  void clear_neighbors() { row_[0] = 0; dirty(); }
 
   template <typename F>
-  void sort(F&& less) { std::sort(begin(), end(), less); }
+  void sort(F&& less) { std::sort(begin(), end(), less); dirty(); }
 
   indexType* begin() { return row_ + 1; }
   indexType* end() { return row_ + 1 + row_[0]; }
 
  private:
+  // every mutation bumps the owning Graph's version: device mirrors of the graph (device_mirror.h) re-upload
+  // when the version they hold is stale
+  void dirty() { if (version_) version_->fetch_add(1, std::memory_order_relaxed); }
   indexType* row_ = nullptr;
   long cap_ = 0;
   indexType owner_ = 0;
+  std::atomic<uint64_t>* version_ = nullptr;
 };
 
 template <typename indexType_>
@@ -125,10 +134,16 @@ struct Graph {
   indexType* data() { return slab_.get(); }
   const indexType* data() const { return slab_.get(); }
 
+  // -- device-mirror bookkeeping (no counterpart upstream): a change counter and the owning handle of the slab.
+  // Writes through data() are not seen by the counter: call touch() after them.
+  uint64_t version() const { return version_ ? version_->load(std::memory_order_relaxed) : 0; }
+  void touch() const { if (version_) version_->fetch_add(1, std::memory_order_relaxed); }
+  const std::shared_ptr<indexType[]>& slab_handle() const { return slab_; }
+
   edgeRange<indexType> operator[](indexType v) const {
     if (v > n_) graph_detail::die("ERROR: graph index out of range: ", (long)v);
     indexType* row = row_ptr(v);
-    return edgeRange<indexType>(row, row + max_deg_ + 1, v);
+    return edgeRange<indexType>(row, row + max_deg_ + 1, v, version_.get());
   }
 
  private:
@@ -138,10 +153,12 @@ struct Graph {
     void* p = aligned_alloc(size_t(1) << 21, bytes);       // 2 MiB aligned like the reference slab (graph.h:136)
     std::memset(p, 0, bytes);
     slab_ = std::shared_ptr<indexType[]>(static_cast<indexType*>(p), std::free);
+    version_ = std::make_shared<std::atomic<uint64_t>>(1);
   }
   size_t n_ = 0;
   long max_deg_ = 0;
   std::shared_ptr<indexType[]> slab_;
+  std::shared_ptr<std::atomic<uint64_t>> version_;   // shared by the (shallow) copies of this Graph, like the slab
 };
 
 }  // namespace parlayANN

@@ -15,6 +15,7 @@
 #pragma once
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <iostream>
@@ -187,17 +188,25 @@ struct hcnng_index {
     t_mst_s += std::chrono::duration<double>(t2 - t1).count();
   }
 
-  // The same build with the trees and Kruskal on the device as well (one pann_hcnng_build call; identical graph).
-  void build_index_on_device(GraphI& G, PointRange& Points, long cluster_rounds, long cluster_size, long MSTDeg) {
-    DI D(Points, nullptr, G.max_degree(), device);
+  // build_index(G, Points, cluster_rounds, cluster_size, MSTDeg)   (:273-281): trees, leaf kNN and Kruskal all on the
+  // device (one pann_hcnng_build call on the mirror of (G, Points)); the edges are appended to G's rows
+  void build_index(GraphI& G, PointRange& Points, long cluster_rounds, long cluster_size, long MSTDeg) {
+    auto L = device_mirror(G, Points);
     double t3[3] = {0, 0, 0};
-    pann_check(pann_hcnng_build(D.h, (uint32_t)cluster_rounds, (uint32_t)cluster_size, (uint32_t)MSTDeg, seed, t3));
+    pann_check(pann_hcnng_build(L.h(), (uint32_t)cluster_rounds, (uint32_t)cluster_size, (uint32_t)MSTDeg, seed, t3));
     t_tree_s += t3[0]; t_leaf_s += t3[1]; t_mst_s += t3[2];
-    D.download_graph(G);
+    MirrorCache::download_graph(L, G);
+    // remove_all_duplicates (:111-114) is a no-op in the reference (remove_edge_duplicates writes back the
+    // unfiltered list, :102-109); kept as such.
+  }
+  void build_index_on_device(GraphI& G, PointRange& Points, long cluster_rounds, long cluster_size, long MSTDeg) {
+    build_index(G, Points, cluster_rounds, cluster_size, MSTDeg);
   }
 
-  // build_index(G, Points, cluster_rounds, cluster_size, MSTDeg)   (:273-281)
-  void build_index(GraphI& G, PointRange& Points, long cluster_rounds, long cluster_size, long MSTDeg) {
+  // The same graph with the reference's host structure kept: cluster tree recursion and Kruskal on the host
+  // (threads over clusters / leaves), the distance work of every level and of every leaf in batched device calls
+  // (pann_pivot_split, pann_leaf_knn_batch).  ~10x slower than build_index at 10M points; a cross-check of it.
+  void build_index_host_tree(GraphI& G, PointRange& Points, long cluster_rounds, long cluster_size, long MSTDeg) {
     DI D(Points, nullptr, G.max_degree(), device);
     for (long r = 0; r < cluster_rounds; r++) {
       std::vector<uint32_t> ids; std::vector<uint64_t> off;
@@ -207,7 +216,7 @@ struct hcnng_index {
       mst_leaves(G, D, ids, off, MSTDeg);
       std::cout << "Built cluster " << r << " of " << cluster_rounds << std::endl;   // clusterEdge.h:151
     }
-    // remove_all_duplicates (:111-114) is a no-op in the reference (see above); kept as such.
+    G.touch();
   }
 };
 

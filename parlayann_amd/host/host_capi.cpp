@@ -13,7 +13,7 @@ static int hcnng_build_t(const void* pts, uint64_t n, uint32_t d, long nc, long 
   hcnng_index<Point, PR, unsigned int> I;
   I.seed = seed;
   I.device = device;
-  I.build_index(G, Points, nc, cs, mst);
+  I.build_index_host_tree(G, Points, nc, cs, mst);
   std::memcpy(graph_out, G.data(), n * (size_t)(nc * mst + 1) * sizeof(uint32_t));
   if (times) { times[0] = I.t_tree_s; times[1] = I.t_leaf_s; times[2] = I.t_mst_s; }
   return 0;

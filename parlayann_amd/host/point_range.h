@@ -2,6 +2,7 @@
 // of euclidian_point.h:92-242 / mips_point.h:67-139.  The views carry the type, metric and
 // parameters; distance arithmetic is NOT done on the host (it lives in libpann.so).
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -99,6 +100,12 @@ struct PointRange {
   }
   byte* location(long i) const { return values.get() + (size_t)i * aligned_bytes; }
 
+  // -- device-mirror bookkeeping (no counterpart upstream): writes through location() / data() are not tracked;
+  // call touch() after changing coordinates in place (normalize_range does)
+  uint64_t version() const { return version_ ? version_->load(std::memory_order_relaxed) : 0; }
+  void touch() const { if (version_) version_->fetch_add(1, std::memory_order_relaxed); }
+  const std::shared_ptr<byte[]>& slab_handle() const { return values; }
+
   parameters params;
 
  private:
@@ -109,8 +116,10 @@ struct PointRange {
     byte* ptr = (byte*)aligned_alloc(1l << 21, total);
     std::memset(ptr, 0, total);
     values = std::shared_ptr<byte[]>(ptr, std::free);
+    version_ = std::make_shared<std::atomic<uint64_t>>(1);
   }
   std::shared_ptr<byte[]> values;
+  std::shared_ptr<std::atomic<uint64_t>> version_;
   unsigned int dims = 0;
   unsigned int aligned_bytes = 0;
   size_t n = 0;

@@ -116,6 +116,7 @@ void normalize_range(FloatRange& pr) {
     const float inv_norm = (float)(1.0 / norm);
     for (long j = 0; j < d; j++) v[j] = v[j] * inv_norm;
   }
+  pr.touch();      // coordinates changed in place: device mirrors of this range are stale
 }
 
 }  // namespace parlayANN

@@ -30,6 +30,12 @@ struct BuildParams {
   double trim = 0.0;
   double rerank_factor = 100;
   std::string alg_type;
+  // this build's additions (no counterpart upstream): the seed that replaces parlay::random_permutation /
+  // std::random_device (DESIGN.md "Build determinism"), the out-neighbour seeding of the self range search
+  // (beamSearch.h:260-262, commented upstream), the host-orchestrated HCNNG cross-check path
+  uint64_t seed = 1;
+  bool use_existing = false;
+  bool host_tree = false;
 
   BuildParams() {}
   // types.h:181-190

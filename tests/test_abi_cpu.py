@@ -33,7 +33,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_capi.QueryParams) == 48          # 4x int64/double + int64 + int32 + float
     assert _capi.QueryParams.limit.offset == 24 and _capi.QueryParams.rerank_factor.offset == 40
     assert C.sizeof(_capi.SearchOut) == 88
-    assert C.sizeof(_capi.BuildStats) == 56
+    assert C.sizeof(_capi.BuildStats) == 72
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
@@ -65,4 +65,15 @@ def test_host_mirror_compiles_without_a_gpu(tmp_path):
     import subprocess
     host = os.path.join(ROOT, "parlayann_amd", "host")
     subprocess.check_call(["make", "-C", host, "-s"])
-    assert os.path.exists(os.path.join(host, "neighbors"))
+    assert os.path.exists(os.path.join(host, "vamana", "neighbors")) and os.path.exists(os.path.join(host, "HCNNG", "neighbors"))
+
+
+def test_reference_signature_tu_compiles_without_a_gpu():
+    """tests/host_api_check.cpp calls the host mirror with the reference's argument lists; it must at least compile and link
+    against the C-ABI library here (it runs under -m gpu, tests/test_host_api_gpu.py)"""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "host_api_check")
+    subprocess.check_call(["g++", "-O0", "-std=c++17", "-pthread", "-Wall", "-Wno-sign-compare", "-o", exe,
+                           os.path.join(ROOT, "tests", "host_api_check.cpp"), "-L" + os.path.join(ROOT, "parlayann_amd", "lib"),
+                           "-lpann", "-Wl,-rpath," + os.path.join(ROOT, "parlayann_amd", "lib")])
+    assert os.path.exists(exe)

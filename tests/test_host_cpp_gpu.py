@@ -1,5 +1,7 @@
-"""The C++ host mirror (parlayann_amd/host/*.h) driven through its example CLI `neighbors`:
-file formats, knn_index::build_index, hcnng_index::build_index, checkRecall -- all over the C-ABI."""
+"""The C++ host mirror (parlayann_amd/host/) driven through the reference-shaped `neighbors` drivers
+(host/vamana/neighbors, host/HCNNG/neighbors = bench/neighborsTime.cpp -> timeNeighbors -> ANN<Point, PointRange,
+indexType>): file formats, knn_index::build_index, hcnng_index::build_index, search_and_parse / checkRecall -- all
+over the C-ABI."""
 import os
 import re
 import subprocess
@@ -17,7 +19,7 @@ HOST = os.path.join(ROOT, "parlayann_amd", "host")
 @pytest.fixture(scope="module")
 def exe():
     subprocess.check_call(["make", "-C", HOST, "-s"])
-    return os.path.join(HOST, "neighbors")
+    return {"vamana": os.path.join(HOST, "vamana", "neighbors"), "hcnng": os.path.join(HOST, "HCNNG", "neighbors")}
 
 
 @pytest.fixture(scope="module")
@@ -31,8 +33,36 @@ def files(tmp_path_factory, oracle):
 
 
 def _run(exe, *args):
-    out = subprocess.run([exe, *[str(a) for a in args]], check=True, capture_output=True, text=True).stdout
-    return out
+    """one run of the driver of `-alg` (default vamana).  Like upstream, -data_type / -dist_func and the algorithm's
+    build parameters are mandatory and a fixed -Q prints its five repetitions only with -verbose: the helper fills
+    those in so that the tests read like the reference's command lines (vamana/scripts/*)."""
+    a = [str(x) for x in args]
+    alg = "vamana"
+    if "-alg" in a:
+        i = a.index("-alg"); alg = a[i + 1]; del a[i:i + 2]
+    if "-device_build" in a:                      # -device_build 0 == the host-tree cross-check path
+        i = a.index("-device_build")
+        if a[i + 1] == "0":
+            a.append("-host_tree")
+        del a[i:i + 2]
+    for flag in ("-self", "-range", "-use_existing", "-normalize", "-verbose"):      # presence flags upstream (getOption)
+        if flag in a:
+            i = a.index(flag)
+            on = a[i + 1] != "0"
+            del a[i:i + 2]
+            if on:
+                a.append(flag)
+    if "-dist_func" not in a:
+        a += ["-dist_func", "Euclidian"]
+    if alg == "vamana":
+        for f, v in (("-R", "64"), ("-L", "128"), ("-alpha", "1.2")):
+            if f not in a:
+                a += [f, v]
+    if "-Q" in a and "-verbose" not in a:
+        a.append("-verbose")
+    r = subprocess.run([exe[alg], *a], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout
 
 
 def test_vamana_cli_builds_the_same_graph_and_reports_recall(exe, files, oracle):
