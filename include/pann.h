@@ -220,6 +220,27 @@ int pann_vamana_insert_batch(pann_index* idx, const uint32_t* batch_ids, uint64_
 int pann_vamana_build(pann_index* idx, uint32_t R, uint32_t L, double alpha, int num_passes,
                       uint64_t seed, int sort_neighbors, pann_build_stats* stats);
 
+/* The two phases of one batch on DEVICE pointers -- the seam of the multi-GPU build (SURVEY.md section 8e row 3;
+ * parlayann_amd/distributed.py): with the points and the graph replicated, every rank runs phase A on its slice of the
+ * batch, the slices' rows are all-gathered (ONE collective per batch, m x R x 4 bytes), and every rank applies the rows of
+ * the whole batch with phase B, which is a deterministic function of (graph, batch ids, rows): all replicas stay identical
+ * and equal to the single-GPU build.  Both calls run on the handle's stream and return after it has drained.
+ *   A: beam search from `start` + robustPrune of the visited list (vamana/index.h:247-266) for the m ids given; reads the
+ *      graph only.  d_rows_out: m x R uint32, unused slots 0xFFFFFFFF.
+ *   B: write the rows (:268-270), reverse edges grouped by target, append-or-re-prune (:278-300). */
+int pann_vamana_search_prune_dev(pann_index* idx, const uint32_t* d_batch_ids, uint64_t m, uint32_t start, uint32_t R, uint32_t L,
+                                 double alpha, uint32_t* d_rows_out, pann_build_stats* stats);
+int pann_vamana_apply_rows_dev(pann_index* idx, const uint32_t* d_batch_ids, uint64_t m, const uint32_t* d_rows, uint32_t R,
+                               double alpha, pann_build_stats* stats);
+/* final neighbour sort of build_index (:180-185), ties by id */
+int pann_vamana_sort_neighbors(pann_index* idx);
+/* host-only helpers (no device needed), so that every rank derives the same schedule: the insertion order of this build
+ * (Fisher-Yates driven by splitmix64(seed), DESIGN.md "Build determinism") and the prefix-doubling batch bounds of
+ * batch_insert (:206-209, :223-234; base 2, max_fraction .02) for m inserts into a graph of n vertices: bounds gets
+ * (floor, ceiling) pairs, at most cap of them; returns the number of batches. */
+void pann_build_permutation(uint64_t n, uint64_t seed, uint32_t* out);
+uint64_t pann_vamana_batch_schedule(uint64_t n, uint64_t m, uint64_t* bounds, uint64_t cap);
+
 /* ---- dense all-pairs: HCNNG leaf (hcnng_index.h:145-181) and ground truth ------------------- */
 
 /* For one leaf given by N ids: for each i the m smallest (dist,id) neighbours among the other
@@ -259,6 +280,26 @@ int pann_range_search(pann_index* idx, const void* queries, const uint32_t* quer
  * DESIGN.md "Build determinism".  times3 (optional): seconds spent in {tree, leaf kNN, MST}. */
 int pann_hcnng_build(pann_index* idx, uint32_t num_clusters, uint32_t cluster_size, uint32_t mst_deg,
                      uint64_t seed, double* times3);
+
+/* Sharded index: d_ids / d_dists hold nlists result lists per query, [nlists][nq][k_in] (global
+ * ids; 0xFFFFFFFF = unused slot) -- the output of one all-gather of every shard's top-k; out = per query the k_out smallest
+ * under (dist, id) (beamSearch.h:46-48).  Device pointers, launched on `stream` of the current device, no synchronisation. */
+int pann_merge_topk_dev(const uint32_t* d_ids, const float* d_dists, uint32_t nlists, uint64_t nq, uint32_t k_in, uint32_t k_out,
+                        uint32_t* d_out_ids, float* d_out_dists, void* stream);
+
+/* HCNNG with the TREES split over GPUs (the cluster trees are independent,
+ * clusterEdge.h:146-153): every rank holds all points; rank r builds trees r, r + W, r + 2W, ... of the forest that
+ * pann_hcnng_build(seed) builds (same per-tree seeds) into a device slab, the slabs are all-gathered (ONE collective) and
+ * every rank interleaves them in tree order: the graph of the single-GPU build, bit for bit.
+ *   build_trees: trees first_tree, first_tree + tree_step, ... (ntrees of them); tree j of the call writes vertex v's edges
+ *     (at most mst_deg, hcnng_index.h:213) into slots [j*mst_deg, (j+1)*mst_deg) of row v of d_slab (device, n rows of
+ *     slab_stride uint32, 0xFFFFFFFF = empty; filled here).  The handle's own graph is not touched.
+ *   assemble: d_slabs = nslabs slabs one after the other (the all-gather's output); slab w holds trees w, w + nslabs, ...;
+ *     row v of the handle's graph gets, after its current neighbours, the edges of trees 0 .. ntrees-1 in tree order. */
+int pann_hcnng_build_trees_dev(pann_index* idx, uint32_t first_tree, uint32_t tree_step, uint32_t ntrees, uint32_t cluster_size,
+                               uint32_t mst_deg, uint64_t seed, uint32_t* d_slab, uint32_t slab_stride, double* times3);
+int pann_hcnng_assemble_dev(pann_index* idx, const uint32_t* d_slabs, uint32_t nslabs, uint32_t slab_stride, uint32_t ntrees,
+                            uint32_t mst_deg);
 
 /* Brute-force k nearest base points for nq external queries (compute_groundtruth.cpp:22-59):
  * out rows sorted by (dist,id). Host pointers. */

@@ -401,14 +401,15 @@ void pann_oracle_set_build_point_stats(uint32_t* visited, uint32_t* dists) { g_p
 
 // One batch of vamana/index.h:188-316 (steps 1-4) on a HOST graph in the reference layout.
 // stats6: [search_dist_cmps, prune_dist_cmps, visited_total, t_search_us, t_prune_us, t_bidirect_us]
-int pann_oracle_vamana_insert_batch(const void* points, uint64_t n, uint32_t d, int dtype,
-                                    uint64_t stride, int metric, uint32_t* graph, uint32_t maxdeg,
-                                    const uint32_t* batch, uint64_t m, uint32_t start, uint32_t R,
-                                    uint32_t L, double alpha, uint64_t* stats6, int nthreads) {
+// The batch in two phases, the split the multi-GPU build makes (tests/test_distributed_cpu.py drives
+// parlayann_amd/distributed.py with these as the per-rank workers): phase A = :247-266 for the points given (reads the
+// graph only), rows_out m x R, unused slots 0xFFFFFFFF; phase B = :268-300 for the whole batch.
+int pann_oracle_vamana_phase_a(const void* points, uint64_t n, uint32_t d, int dtype, uint64_t stride, int metric,
+                               const uint32_t* graph, uint32_t maxdeg, const uint32_t* batch, uint64_t m, uint32_t start,
+                               uint32_t R, uint32_t L, double alpha, uint32_t* rows_out, uint64_t* stats6, int nthreads) {
   if (R > maxdeg) return 1;
-  Dataset D{(const uint8_t*)points, n, d, dtype, stride, metric, graph, maxdeg};
+  Dataset D{(const uint8_t*)points, n, d, dtype, stride, metric, const_cast<uint32_t*>(graph), maxdeg};
   SearchParams QP{0, (int64_t)L, 0.0, (int64_t)n, (int64_t)maxdeg};  // :250
-  std::vector<std::vector<uint32_t>> new_out(m);
   std::atomic<uint64_t> sdc(0), pdc(0), vis(0);
   auto t0 = std::chrono::steady_clock::now();
   parallel_for(0, m, nthreads, [&](size_t i) {  // :247-266
@@ -418,23 +419,42 @@ int pann_oracle_vamana_insert_batch(const void* points, uint64_t n, uint32_t d, 
     sdc += Rs.dist_cmps; vis += Rs.visited.size();
     uint64_t dc = 0;
     std::vector<IdDist> cand = Rs.visited;
-    robust_prune(D, p, cand, alpha, R, true, new_out[i], &dc);
+    std::vector<uint32_t> out;
+    robust_prune(D, p, cand, alpha, R, true, out, &dc);
     pdc += dc;
     if (g_pp_visited) g_pp_visited[p] += (uint32_t)Rs.visited.size();     // one writer per p within a batch
     if (g_pp_dists) g_pp_dists[p] += (uint32_t)(Rs.dist_cmps + dc);
+    for (uint32_t j = 0; j < R; j++) rows_out[i * (uint64_t)R + j] = j < out.size() ? out[j] : 0xFFFFFFFFu;
   });
+  if (stats6) {
+    stats6[0] += sdc; stats6[1] += pdc; stats6[2] += vis;
+    stats6[3] += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+  }
+  return 0;
+}
+
+int pann_oracle_vamana_phase_b(const void* points, uint64_t n, uint32_t d, int dtype, uint64_t stride, int metric,
+                               uint32_t* graph, uint32_t maxdeg, const uint32_t* batch, uint64_t m, const uint32_t* rows,
+                               uint32_t R, double alpha, uint64_t* stats6, int nthreads) {
+  if (R > maxdeg) return 1;
+  Dataset D{(const uint8_t*)points, n, d, dtype, stride, metric, graph, maxdeg};
+  std::atomic<uint64_t> pdc(0);
   auto t1 = std::chrono::steady_clock::now();
   const uint64_t rs = (uint64_t)maxdeg + 1;
+  auto row_len = [&](size_t i) { uint32_t c = 0; while (c < R && rows[i * (uint64_t)R + c] != 0xFFFFFFFFu) c++; return c; };
   parallel_for(0, m, nthreads, [&](size_t i) {  // :268-270
     uint32_t* row = graph + batch[i] * rs;
-    row[0] = (uint32_t)new_out[i].size();
-    for (size_t j = 0; j < new_out[i].size(); j++) row[1 + j] = new_out[i][j];
+    const uint32_t c = row_len(i);
+    row[0] = c;
+    for (uint32_t j = 0; j < c; j++) row[1 + j] = rows[i * (uint64_t)R + j];
   });
   // :278-282 reverse edges grouped by target.  Order inside a group (unspecified upstream):
   // ascending position of the source in the batch -- the rule the product follows too.
   std::vector<std::pair<uint32_t, uint32_t>> edges;  // (target, batch position)
-  for (size_t i = 0; i < m; i++)
-    for (uint32_t v : new_out[i]) edges.push_back({v, (uint32_t)i});
+  for (size_t i = 0; i < m; i++) {
+    const uint32_t c = row_len(i);
+    for (uint32_t j = 0; j < c; j++) edges.push_back({rows[i * (uint64_t)R + j], (uint32_t)i});
+  }
   std::sort(edges.begin(), edges.end());
   std::vector<size_t> gstart;
   for (size_t e = 0; e < edges.size(); e++)
@@ -468,10 +488,19 @@ int pann_oracle_vamana_insert_batch(const void* points, uint64_t n, uint32_t d, 
   auto t3 = std::chrono::steady_clock::now();
   if (stats6) {
     auto us = [](auto a, auto b) { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
-    stats6[0] += sdc; stats6[1] += pdc; stats6[2] += vis;
-    stats6[3] += us(t0, t1); stats6[4] += us(t2, t3); stats6[5] += us(t1, t2);
+    stats6[1] += pdc; stats6[4] += us(t2, t3); stats6[5] += us(t1, t2);
   }
   return 0;
+}
+
+int pann_oracle_vamana_insert_batch(const void* points, uint64_t n, uint32_t d, int dtype,
+                                    uint64_t stride, int metric, uint32_t* graph, uint32_t maxdeg,
+                                    const uint32_t* batch, uint64_t m, uint32_t start, uint32_t R,
+                                    uint32_t L, double alpha, uint64_t* stats6, int nthreads) {
+  std::vector<uint32_t> rows((size_t)m * R);
+  if (int rc = pann_oracle_vamana_phase_a(points, n, d, dtype, stride, metric, graph, maxdeg, batch, m, start, R, L, alpha,
+                                          rows.data(), stats6, nthreads)) return rc;
+  return pann_oracle_vamana_phase_b(points, n, d, dtype, stride, metric, graph, maxdeg, batch, m, rows.data(), R, alpha, stats6, nthreads);
 }
 
 // vamana/index.h:150-186 build_index + the batch schedule of :200-234.

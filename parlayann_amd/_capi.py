@@ -87,6 +87,13 @@ SIGNATURES = {
                                            C.c_double, C.POINTER(BuildStats)]),
     "pann_vamana_build": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_double, C.c_int, C.c_uint64, C.c_int,
                                     C.POINTER(BuildStats)]),
+    "pann_vamana_search_prune_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                               C.c_double, C.c_void_p, C.POINTER(BuildStats)]),
+    "pann_vamana_apply_rows_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_double,
+                                             C.POINTER(BuildStats)]),
+    "pann_vamana_sort_neighbors": (C.c_int, [C.c_void_p]),
+    "pann_build_permutation": (None, [C.c_uint64, C.c_uint64, C.c_void_p]),
+    "pann_vamana_batch_schedule": (C.c_uint64, [C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64]),
     "pann_leaf_knn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "pann_leaf_knn_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
                                       C.c_void_p]),
@@ -94,6 +101,11 @@ SIGNATURES = {
                               C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
     "pann_pivot_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pann_hcnng_build": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p]),
+    "pann_merge_topk_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
+    "pann_hcnng_build_trees_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
+                                             C.c_void_p, C.c_uint32, C.c_void_p]),
+    "pann_hcnng_assemble_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "pann_bruteforce_knn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p,
                                       C.c_void_p]),
 }

@@ -66,7 +66,7 @@ struct pann_index {
   DeviceIndex ix;
   int device = 0;
   hipStream_t stream = nullptr;
-  Workspace ws, ws2, ws3;   // kernel scratch (search / prune / re-prune)
+  Workspace ws, ws2, ws3, ws4;   // kernel scratch (search / prune / re-prune / rows of a batch)
   uint32_t vcap = 0;        // visited-list capacity used by the builder (grows on overflow)
   uint32_t dcap = 256;      // dropped-list capacity of the searches (pann_index_reserve_dropped; grows on overflow)
   DevBuf stage[12];      // staging for host-pointer calls
@@ -238,7 +238,7 @@ void pann_index_destroy(pann_index* idx) {
   if (idx->stream) (void)hipStreamSynchronize(idx->stream);
   if (idx->ix.points) (void)hipFree(idx->ix.points);
   if (idx->ix.graph) (void)hipFree(idx->ix.graph);
-  idx->ws.release(); idx->ws2.release(); idx->ws3.release();
+  idx->ws.release(); idx->ws2.release(); idx->ws3.release(); idx->ws4.release();
   for (auto& s : idx->stage) s.release();
   idx->pin_in.release(); idx->pin_out.release();
   if (idx->stream) (void)hipStreamDestroy(idx->stream);
@@ -460,8 +460,39 @@ int pann_vamana_insert_batch(pann_index* idx, const uint32_t* batch_ids, uint64_
   if (int rc = idx->stage[2].ensure(m * 4)) return rc;
   PANN_HIP(hipMemcpyAsync(idx->stage[2].p, batch_ids, m * 4, hipMemcpyHostToDevice, idx->stream));
   if (idx->vcap < default_vcap(L)) idx->vcap = default_vcap(L);
-  return insert_batch_dev(idx->ix, idx->ws2, idx->ws3, idx->ws, idx->stream, idx->stage[2].as<uint32_t>(), (uint32_t)m,
+  return insert_batch_dev(idx->ix, idx->ws2, idx->ws3, idx->ws, idx->ws4, idx->stream, idx->stage[2].as<uint32_t>(), (uint32_t)m,
                           start, R, L, alpha, &idx->vcap, stats);
+}
+
+// ---- the two phases of a batch on device pointers: the seam of the multi-GPU build (parlayann_amd/distributed.py) ----
+
+int pann_vamana_search_prune_dev(pann_index* idx, const uint32_t* d_batch_ids, uint64_t m, uint32_t start, uint32_t R, uint32_t L,
+                                 double alpha, uint32_t* d_rows_out, pann_build_stats* stats) {
+  if (int rc = check_idx(idx, "pann_vamana_search_prune_dev")) return rc;
+  if (m == 0) return PANN_OK;
+  if (!d_batch_ids || !d_rows_out) { set_error("pann_vamana_search_prune_dev: null argument"); return PANN_ERR_BAD_ARG; }
+  if (L == 0 || L > 65536) { set_error("pann_vamana_search_prune_dev: L out of range"); return PANN_ERR_BAD_ARG; }
+  if (start >= idx->ix.n || m > 0xFFFFFFF0ull) { set_error("pann_vamana_search_prune_dev: start / batch size out of range"); return PANN_ERR_BAD_ARG; }
+  DeviceGuard g(idx->device);
+  if (idx->vcap < default_vcap(L)) idx->vcap = default_vcap(L);
+  return vamana_search_prune_dev(idx->ix, idx->ws2, idx->ws, idx->stream, d_batch_ids, (uint32_t)m, start, R, L, alpha, &idx->vcap,
+                                 d_rows_out, stats);
+}
+
+int pann_vamana_apply_rows_dev(pann_index* idx, const uint32_t* d_batch_ids, uint64_t m, const uint32_t* d_rows, uint32_t R,
+                               double alpha, pann_build_stats* stats) {
+  if (int rc = check_idx(idx, "pann_vamana_apply_rows_dev")) return rc;
+  if (m == 0) return PANN_OK;
+  if (!d_batch_ids || !d_rows) { set_error("pann_vamana_apply_rows_dev: null argument"); return PANN_ERR_BAD_ARG; }
+  if (m > 0xFFFFFFF0ull) { set_error("pann_vamana_apply_rows_dev: batch too large"); return PANN_ERR_BAD_ARG; }
+  DeviceGuard g(idx->device);
+  return vamana_apply_rows_dev(idx->ix, idx->ws2, idx->ws3, idx->stream, d_batch_ids, (uint32_t)m, d_rows, R, alpha, stats);
+}
+
+int pann_vamana_sort_neighbors(pann_index* idx) {
+  if (int rc = check_idx(idx, "pann_vamana_sort_neighbors")) return rc;
+  DeviceGuard g(idx->device);
+  return sort_neighbors_dev(idx->ix, idx->stream);
 }
 
 // the insertion order of this build: Fisher-Yates driven by splitmix64(seed) (DESIGN.md "Build
@@ -477,6 +508,37 @@ static void build_permutation(uint64_t m, uint64_t seed, std::vector<uint32_t>& 
     return z ^ (z >> 31);
   };
   for (uint64_t i = m; i > 1; i--) std::swap(out[i - 1], out[next() % i]);
+}
+
+void pann_build_permutation(uint64_t n, uint64_t seed, uint32_t* out) {
+  if (!out) return;
+  std::vector<uint32_t> p;
+  build_permutation(n, seed, p);
+  std::memcpy(out, p.data(), n * 4);
+}
+
+uint64_t pann_vamana_batch_schedule(uint64_t n, uint64_t m, uint64_t* bounds, uint64_t cap) {
+  // vamana/index.h:206-209, :223-234 with base 2 and max_fraction .02 (the values build_index passes, :174-177)
+  size_t max_batch = std::min<size_t>((size_t)(0.02 * (double)(float)n), 1000000ul);
+  if (max_batch == 0) max_batch = n;
+  uint64_t nb = 0;
+  size_t count = 0, inc = 0;
+  while (count < m) {
+    size_t floor, ceiling;
+    if (std::pow(2.0, (double)inc) <= (double)max_batch) {
+      floor = (size_t)std::pow(2.0, (double)inc) - 1;
+      ceiling = std::min((size_t)std::pow(2.0, (double)(inc + 1)) - 1, (size_t)m);
+      count = ceiling;
+    } else {
+      floor = count;
+      ceiling = std::min(count + max_batch, (size_t)m);
+      count += max_batch;
+    }
+    if (bounds && nb < cap) { bounds[2 * nb] = floor; bounds[2 * nb + 1] = ceiling; }
+    nb++;
+    inc++;
+  }
+  return nb;
 }
 
 int pann_vamana_build(pann_index* idx, uint32_t R, uint32_t L, double alpha, int num_passes, uint64_t seed,
@@ -509,7 +571,7 @@ int pann_vamana_build(pann_index* idx, uint32_t R, uint32_t L, double alpha, int
         ceiling = std::min(count + max_batch, (size_t)n);
         count += max_batch;
       }
-      if (int rc = insert_batch_dev(idx->ix, idx->ws2, idx->ws3, idx->ws, idx->stream, d_perm + floor,
+      if (int rc = insert_batch_dev(idx->ix, idx->ws2, idx->ws3, idx->ws, idx->ws4, idx->stream, d_perm + floor,
                                     (uint32_t)(ceiling - floor), 0u /* set_start(): vertex 0, :148 */, R, L, a,
                                     &idx->vcap, stats))
         return rc;
@@ -747,6 +809,26 @@ int pann_range_search(pann_index* idx, const void* queries, const uint32_t* quer
   return PANN_OK;
 }
 
+
+int pann_hcnng_build_trees_dev(pann_index* idx, uint32_t first_tree, uint32_t tree_step, uint32_t ntrees, uint32_t cluster_size,
+                               uint32_t mst_deg, uint64_t seed, uint32_t* d_slab, uint32_t slab_stride, double* times3) {
+  if (int rc = check_idx(idx, "pann_hcnng_build_trees_dev")) return rc;
+  if (mst_deg == 0 || tree_step == 0 || !d_slab) { set_error("pann_hcnng_build_trees_dev: null / zero argument"); return PANN_ERR_BAD_ARG; }
+  DeviceGuard g(idx->device);
+  hipLaunchKernelGGL(fill_u32_kernel, dim3(2048), dim3(256), 0, idx->stream, d_slab, idx->ix.n * (uint64_t)slab_stride, SENTINEL);
+  PANN_HIP(hipGetLastError());
+  if (ntrees == 0) { PANN_HIP(hipStreamSynchronize(idx->stream)); return PANN_OK; }
+  return hcnng_build_dev(idx->ix, idx->ws2, idx->stream, ntrees, cluster_size, mst_deg, seed, times3, first_tree, tree_step, d_slab, slab_stride);
+}
+
+int pann_hcnng_assemble_dev(pann_index* idx, const uint32_t* d_slabs, uint32_t nslabs, uint32_t slab_stride, uint32_t ntrees,
+                            uint32_t mst_deg) {
+  if (int rc = check_idx(idx, "pann_hcnng_assemble_dev")) return rc;
+  if (!d_slabs || mst_deg == 0) { set_error("pann_hcnng_assemble_dev: null / zero argument"); return PANN_ERR_BAD_ARG; }
+  if ((uint64_t)ntrees * mst_deg > idx->ix.max_deg) { set_error("pann_hcnng_assemble_dev: max_deg < ntrees * mst_deg"); return PANN_ERR_BAD_ARG; }
+  DeviceGuard g(idx->device);
+  return hcnng_assemble_dev(idx->ix, idx->stream, d_slabs, nslabs, slab_stride, ntrees, mst_deg);
+}
 
 int pann_hcnng_build(pann_index* idx, uint32_t num_clusters, uint32_t cluster_size, uint32_t mst_deg, uint64_t seed,
                      double* times3) {

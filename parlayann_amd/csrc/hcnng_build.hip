@@ -291,6 +291,48 @@ int dense_topk_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, const u
                    const uint32_t* d_tile_seg, const uint32_t* d_tile_a0, uint32_t ntiles, uint64_t na, uint64_t nb,
                    uint32_t nsplit, uint32_t m, int exclude_same, uint32_t* d_out_ids, float* d_out_dists);
 
+__global__ void fill_u32_hc(uint32_t* p, uint64_t n, uint32_t v) {
+  const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// Tree-parallel HCNNG, assembly: slabs[w] (n rows of slab_stride slots) holds rank w's trees w, w + W, w + 2W, ... in slots
+// [j*mst_deg, (j+1)*mst_deg) of every row.  Row v of the graph = the edges of trees 0, 1, 2, ... in that order (the append order
+// of the single-process build, hcnng_index.h:117-131), continuing after the row's current neighbours.  One wave per vertex.
+__global__ void __launch_bounds__(PANN_WAVE) hcnng_assemble_kernel(uint32_t* graph, uint32_t gstride, uint32_t max_deg, const uint32_t* slabs,
+                                                                   uint64_t n, uint32_t W, uint32_t slab_stride, uint32_t ntrees,
+                                                                   uint32_t mst_deg) {
+  const uint64_t v = blockIdx.x;
+  const int lane = threadIdx.x;
+  uint32_t* row = graph + v * gstride;
+  uint32_t deg = 0;
+  for (uint32_t i0 = 0; i0 < gstride; i0 += PANN_WAVE) {
+    const uint32_t i = i0 + lane;
+    deg += __popcll(__ballot(i < gstride && row[i] != SENTINEL));
+  }
+  for (uint32_t t = 0; t < ntrees; t++) {
+    const uint32_t* src = slabs + ((uint64_t)(t % W) * n + v) * slab_stride + (uint64_t)(t / W) * mst_deg;
+    for (uint32_t i0 = 0; i0 < mst_deg; i0 += PANN_WAVE) {
+      const uint32_t i = i0 + lane;
+      const uint32_t a = i < mst_deg ? src[i] : SENTINEL;
+      const uint64_t am = __ballot(a != SENTINEL);
+      const uint32_t pos = deg + lanes_below(am, lane);
+      if (a != SENTINEL && pos < max_deg) row[pos] = a;                 // process_edges: rows never exceed maxDeg (:121-124)
+      deg = min(deg + (uint32_t)__popcll(am), max_deg);
+    }
+  }
+}
+
+int hcnng_assemble_dev(const DeviceIndex& ix, hipStream_t st, const uint32_t* d_slabs, uint32_t W, uint32_t slab_stride,
+                       uint32_t ntrees, uint32_t mst_deg) {
+  if (W == 0 || (uint64_t)((ntrees + W - 1) / W) * mst_deg > slab_stride) { set_error("pann_hcnng_assemble_dev: slab rows too short"); return PANN_ERR_BAD_ARG; }
+  hipLaunchKernelGGL(hcnng_assemble_kernel, dim3((uint32_t)ix.n), dim3(PANN_WAVE), 0, st, ix.graph, ix.gstride, ix.max_deg, d_slabs,
+                     ix.n, W, slab_stride, ntrees, mst_deg);
+  PANN_HIP(hipGetLastError());
+  PANN_HIP(hipStreamSynchronize(st));
+  return PANN_OK;
+}
+
 struct HBuf {   // small RAII device buffer
   void* p = nullptr;
   ~HBuf() { if (p) (void)hipFree(p); }
@@ -298,12 +340,19 @@ struct HBuf {   // small RAII device buffer
   template <typename T> T* as() { return (T*)p; }
 };
 
+// Trees first_tree, first_tree + tree_step, ... (num_clusters of them) of the forest seeded by `seed` (tree t: mix(mix(seed + t))).
+// slab == nullptr: the edges are appended to the index's graph rows (pann_hcnng_build).  slab != nullptr (tree-parallel build over
+// ranks): tree j of THIS call writes vertex v's edges into slots [j*mst_deg, (j+1)*mst_deg) of row v of the slab (n rows of
+// slab_stride uint32, SENTINEL = empty) -- a vertex gains at most mst_deg edges per tree (hcnng_index.h:213) -- so the trees of all
+// ranks can be interleaved in tree order afterwards (hcnng_assemble_dev).
 int hcnng_build_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, uint32_t num_clusters, uint32_t cluster_size,
-                    uint32_t mst_deg, uint64_t seed, double* times3) {
+                    uint32_t mst_deg, uint64_t seed, double* times3, uint32_t first_tree, uint32_t tree_step, uint32_t* slab,
+                    uint32_t slab_stride) {
   const uint64_t n = ix.n;
   const uint32_t m = 10;                                  // hcnng_index.h:140
   if (cluster_size < 2 || cluster_size > 65535) { set_error("pann_hcnng_build: cluster_size must be in [2,65535]"); return PANN_ERR_BAD_ARG; }
-  if ((uint64_t)num_clusters * mst_deg > ix.max_deg) { set_error("pann_hcnng_build: max_deg < num_clusters * mst_deg"); return PANN_ERR_BAD_ARG; }
+  if (!slab && (uint64_t)num_clusters * mst_deg > ix.max_deg) { set_error("pann_hcnng_build: max_deg < num_clusters * mst_deg"); return PANN_ERR_BAD_ARG; }
+  if (slab && (uint64_t)num_clusters * mst_deg > slab_stride) { set_error("pann_hcnng_build_trees: slab rows shorter than ntrees * mst_deg"); return PANN_ERR_BAD_ARG; }
   if (mst_deg > 255) { set_error("pann_hcnng_build: mst_deg > 255"); return PANN_ERR_BAD_ARG; }
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto secs = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
@@ -348,7 +397,8 @@ int hcnng_build_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, uint32
     const uint64_t tot = (uint64_t)ng * n;
     hipLaunchKernelGGL(iota_mod_u32, dim3((uint32_t)((tot + 255) / 256)), dim3(256), 0, st, fids, tot, (uint32_t)n);
     std::vector<Cl> level;
-    for (uint32_t j = 0; j < ng; j++) level.push_back(Cl{(uint32_t)(j * n), (uint32_t)n, hc_mix_host(hc_mix_host(seed + tg + j))});
+    for (uint32_t j = 0; j < ng; j++)
+      level.push_back(Cl{(uint32_t)(j * n), (uint32_t)n, hc_mix_host(hc_mix_host(seed + first_tree + (uint64_t)(tg + j) * tree_step))});
     while (!level.empty()) {
       std::vector<SplitCluster> sc; std::vector<Cl> src;
       for (const Cl& c : level) {
@@ -447,6 +497,10 @@ int hcnng_build_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, uint32
     MstArgs ma{};
     ma.keys = b_kb.as<uint64_t>(); ma.leaf_off = d_loff.as<uint64_t>(); ma.nleaves = nleaves; ma.m = m; ma.ids = ids;
     ma.graph = ix.graph; ma.gstride = ix.gstride; ma.max_deg = ix.max_deg; ma.deg = b_deg.as<uint32_t>(); ma.mst_deg = mst_deg;
+    if (slab) {   // slotted rows: local tree tg + j owns slots [(tg+j)*mst_deg, (tg+j+1)*mst_deg)
+      hipLaunchKernelGGL(fill_u32_hc, dim3(nb256), dim3(256), 0, st, b_deg.as<uint32_t>(), n, (tg + j) * mst_deg);
+      ma.graph = slab; ma.gstride = slab_stride; ma.max_deg = (tg + j + 1) * mst_deg;
+    }
     ma.g_parent = b_par.as<int32_t>(); ma.g_rank = b_rnk.as<uint8_t>(); ma.g_degree = b_dgr.as<uint8_t>();
     uint64_t max_leaf = 2;
     for (uint32_t l = 0; l < nleaves; l++) max_leaf = std::max<uint64_t>(max_leaf, leaf_off[l + 1] - leaf_off[l]);

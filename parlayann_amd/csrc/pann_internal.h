@@ -71,9 +71,16 @@ int robust_prune_batch_host(const DeviceIndex& ix, Workspace& ws, hipStream_t st
                             uint64_t m, const uint32_t* cand_ids, const float* cand_dists,
                             const uint64_t* cand_offsets, double alpha, uint32_t R, int add_out_nbrs,
                             uint32_t* out_rows, uint32_t* out_dist_cmps);
-int insert_batch_dev(const DeviceIndex& ix, Workspace& ws, Workspace& ws2, Workspace& search_ws, hipStream_t st,
+int insert_batch_dev(const DeviceIndex& ix, Workspace& ws, Workspace& ws2, Workspace& search_ws, Workspace& rows_ws, hipStream_t st,
                      const uint32_t* d_batch, uint32_t m, uint32_t start, uint32_t R, uint32_t L, double alpha,
                      uint32_t* vcap_io, pann_build_stats* stats);
+// the two phases of a batch (vamana_build.hip): A reads the graph and yields rows for the points given, B applies the
+// rows of the whole batch; d_rows is m x R uint32, SENTINEL padded
+int vamana_search_prune_dev(const DeviceIndex& ix, Workspace& ws, Workspace& search_ws, hipStream_t st, const uint32_t* d_batch,
+                            uint32_t m, uint32_t start, uint32_t R, uint32_t L, double alpha, uint32_t* vcap_io,
+                            uint32_t* d_rows, pann_build_stats* stats);
+int vamana_apply_rows_dev(const DeviceIndex& ix, Workspace& ws, Workspace& ws2, hipStream_t st, const uint32_t* d_batch, uint32_t m,
+                          const uint32_t* d_rows, uint32_t R, double alpha, pann_build_stats* stats);
 int sort_neighbors_dev(const DeviceIndex& ix, hipStream_t st);
 
 // dense.hip
@@ -101,6 +108,9 @@ int range_search_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, const
 
 // hcnng_build.hip
 int hcnng_build_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, uint32_t num_clusters, uint32_t cluster_size,
-                    uint32_t mst_deg, uint64_t seed, double* times3);
+                    uint32_t mst_deg, uint64_t seed, double* times3, uint32_t first_tree = 0, uint32_t tree_step = 1,
+                    uint32_t* slab = nullptr, uint32_t slab_stride = 0);
+int hcnng_assemble_dev(const DeviceIndex& ix, hipStream_t st, const uint32_t* d_slabs, uint32_t W, uint32_t slab_stride,
+                       uint32_t ntrees, uint32_t mst_deg);
 
 }  // namespace pann

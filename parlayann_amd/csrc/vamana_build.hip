@@ -601,39 +601,40 @@ int robust_prune_batch_host(const DeviceIndex& ix, Workspace& ws, hipStream_t st
   return PANN_OK;
 }
 
-// One batch of batch_insert (:242-300), everything on the device.  d_batch: m vertex ids.
-int insert_batch_dev(const DeviceIndex& ix, Workspace& ws, Workspace& ws2, Workspace& search_ws, hipStream_t st,
-                     const uint32_t* d_batch, uint32_t m, uint32_t start, uint32_t R, uint32_t L, double alpha,
-                     uint32_t* vcap_io, pann_build_stats* stats) {
+// One batch of batch_insert (:242-300) on the device, in two phases so that the batch can be split over GPUs
+// (parlayann_amd/distributed.py):
+//   phase A  vamana_search_prune_dev : beam search from `start` + robustPrune of the visited list for the batch points
+//            handed in (:247-266) -- reads the graph only, so any subset of the batch can run anywhere; result = their new
+//            out-neighbour rows, m x R, SENTINEL padded
+//   phase B  vamana_apply_rows_dev   : write the rows of the WHOLE batch (:268-270), then the reverse edges grouped by
+//            target, append-or-re-prune (:278-300) -- a deterministic function of (graph, batch ids, rows)
+// insert_batch_dev = A then B on one device.
+namespace {
+auto now_ = [] { return std::chrono::steady_clock::now(); };
+template <class A, class B> double secs_(A a, B b) { return std::chrono::duration<double>(b - a).count(); }
+}  // namespace
+
+int vamana_search_prune_dev(const DeviceIndex& ix, Workspace& ws, Workspace& search_ws, hipStream_t st, const uint32_t* d_batch,
+                            uint32_t m, uint32_t start, uint32_t R, uint32_t L, double alpha, uint32_t* vcap_io,
+                            uint32_t* d_rows, pann_build_stats* stats) {
   if (m == 0) return PANN_OK;
   if (R == 0 || R > ix.max_deg || R > 1024) { set_error("vamana insert: R must be in [1, min(max_deg,1024)]"); return PANN_ERR_BAD_ARG; }
-  auto now = [] { return std::chrono::steady_clock::now(); };
-  auto secs = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
-  const auto t0 = now();
+  const auto t0 = now_();
   uint32_t vcap = *vcap_io;
   for (int attempt = 0;; attempt++) {
     const uint32_t seg_stride = vcap + ix.gstride;
     const uint64_t total_keys = (uint64_t)m * seg_stride;
-    const uint64_t total_edges = (uint64_t)m * R;
     if (total_keys >= 0xFFFFFFF0ull) { set_error("vamana insert: batch too large"); return PANN_ERR_BAD_ARG; }
-    const size_t stmp = std::max({seg_sort_temp_bytes((uint32_t)total_keys, m), sort_temp_bytes((uint32_t)total_edges),
-                                  scan_temp_bytes((uint32_t)total_edges)});
-    uint32_t *d_start, *d_vis_ids, *d_vis_cnt, *d_dcs, *d_seg, *d_send, *d_rows, *d_rcnt, *d_dc, *d_heads, *d_gidx,
-        *d_gstart, *d_src, *d_hown, *d_hcnt, *d_hlen, *d_scalars;
-    float* d_vis_d; uint64_t *d_base, *ka, *kb, *ek_a, *ek_b, *d_hbase; void* d_tmp;
+    const size_t stmp = seg_sort_temp_bytes((uint32_t)total_keys, m);
+    uint32_t *d_start, *d_vis_ids, *d_vis_cnt, *d_dcs, *d_seg, *d_send, *d_rcnt, *d_dc;
+    float* d_vis_d; uint64_t *d_base, *ka, *kb; void* d_tmp;
     auto layout = [&](Bump& b) {
-      d_scalars = b.take<uint32_t>(64);   // [0] status mirror, [1] nvalid, [2] ngroups, [3] nheavy, [4] last head
       d_start = b.take<uint32_t>(4);
       d_vis_ids = b.take<uint32_t>((size_t)m * vcap); d_vis_d = b.take<float>((size_t)m * vcap);
       d_vis_cnt = b.take<uint32_t>(m); d_dcs = b.take<uint32_t>(m);
       d_base = b.take<uint64_t>(m); d_seg = b.take<uint32_t>(m); d_send = b.take<uint32_t>(m);
       ka = b.take<uint64_t>(total_keys + 1); kb = b.take<uint64_t>(total_keys + 1);
-      d_rows = b.take<uint32_t>(total_edges); d_rcnt = b.take<uint32_t>(m); d_dc = b.take<uint32_t>(m);
-      ek_a = b.take<uint64_t>(total_edges + 1); ek_b = b.take<uint64_t>(total_edges + 1);
-      d_heads = b.take<uint32_t>(total_edges + 1); d_gidx = b.take<uint32_t>(total_edges + 1);
-      d_gstart = b.take<uint32_t>(total_edges + 1); d_src = b.take<uint32_t>(total_edges + 1);
-      d_hown = b.take<uint32_t>(total_edges + 1); d_hbase = b.take<uint64_t>(total_edges + 1);
-      d_hcnt = b.take<uint32_t>(total_edges + 1); d_hlen = b.take<uint32_t>(total_edges + 1);
+      d_rcnt = b.take<uint32_t>(m); d_dc = b.take<uint32_t>(m);
       d_tmp = b.take<uint8_t>(stmp + 16);
     };
     Bump dry(nullptr, 0); layout(dry);
@@ -653,11 +654,11 @@ int insert_batch_dev(const DeviceIndex& ix, Workspace& ws, Workspace& ws2, Works
     uint32_t status = 0;
     PANN_HIP(hipMemcpyAsync(&status, (uint8_t*)search_ws.buf + 64, 4, hipMemcpyDeviceToHost, st));
     PANN_HIP(hipStreamSynchronize(st));
-    if (status & 1u) {   // a visited list did not fit: grow and redo the batch (graph untouched so far)
+    if (status & 1u) {   // a visited list did not fit: grow and redo the searches (nothing written so far)
       if (attempt >= 6) { set_error("vamana insert: visited lists keep overflowing"); return PANN_ERR_OVERFLOW; }
       vcap *= 2; *vcap_io = vcap; continue;
     }
-    const auto t1 = now();
+    const auto t1 = now_();
 
     // ---- 2. robustPrune(index, visited) for every batch point (:264) ----
     hipLaunchKernelGGL(fixed_stride_setup_kernel, dim3((m + 255) / 256), dim3(256), 0, st, d_base, d_seg, m, vcap, seg_stride);
@@ -672,82 +673,8 @@ int insert_batch_dev(const DeviceIndex& ix, Workspace& ws, Workspace& ws2, Works
     ga.rows_out = d_rows; ga.rows_stride = R; ga.cnt_out = d_rcnt; ga.graph = nullptr; ga.gstride = ix.gstride;
     ga.dcmps = d_dc; ga.m = m;
     if (int rc = run_prune(ix, pa, ga, ka, kb, (uint32_t)total_keys, d_tmp, stmp, st, seg_stride)) return rc;
-    // ---- :268-270 write the new out-neighbourhoods (only now: searches and prunes saw the old graph)
-    hipLaunchKernelGGL(scatter_rows_kernel, dim3(m), dim3(PANN_WAVE), 0, st, ix.graph, ix.gstride, d_batch, d_rows, R, m);
-    PANN_HIP(hipGetLastError());
     PANN_HIP(hipStreamSynchronize(st));
-    const auto t2 = now();
-
-    // ---- 3. reverse edges grouped by target (:278-282) ----
-    const uint32_t te = (uint32_t)total_edges;
-    hipLaunchKernelGGL(edge_keys_kernel, dim3((te + 255) / 256), dim3(256), 0, st, d_rows, R, m, ek_a);
-    size_t tb = stmp;
-    PANN_HIP(rocprim::radix_sort_keys(d_tmp, tb, ek_a, ek_b, te, 0, 64, st));
-    PANN_HIP(hipMemsetAsync(d_scalars, 0, 256, st));
-    hipLaunchKernelGGL(edge_heads_kernel, dim3((te + 255) / 256), dim3(256), 0, st, ek_b, (uint64_t)te, d_heads, d_scalars + 1);
-    tb = stmp;
-    PANN_HIP(rocprim::exclusive_scan(d_tmp, tb, d_heads, d_gidx, 0u, te, rocprim::plus<uint32_t>(), st));
-    hipLaunchKernelGGL(group_starts_kernel, dim3((te + 255) / 256), dim3(256), 0, st, d_heads, d_gidx, (uint64_t)te, d_gstart);
-    uint32_t h_last[2];
-    PANN_HIP(hipMemcpyAsync(&h_last[0], d_gidx + (te - 1), 4, hipMemcpyDeviceToHost, st));
-    PANN_HIP(hipMemcpyAsync(&h_last[1], d_heads + (te - 1), 4, hipMemcpyDeviceToHost, st));
-    PANN_HIP(hipStreamSynchronize(st));
-    const uint32_t ngroups = h_last[0] + h_last[1];
-    PANN_HIP(hipMemcpyAsync(d_scalars + 2, &ngroups, 4, hipMemcpyHostToDevice, st));
-    const auto t3 = now();
-
-    // ---- 4. append or re-prune per target (:289-300) ----
-    uint32_t nheavy = 0;
-    if (ngroups) {
-      ReverseArgs ra{};
-      ra.graph = ix.graph; ra.gstride = ix.gstride; ra.R = R; ra.ekeys = ek_b; ra.gstart = d_gstart;
-      ra.ngroups = d_scalars + 2; ra.nvalid = d_scalars + 1; ra.batch = d_batch; ra.edge_src = d_src;
-      ra.heavy_owner = d_hown; ra.heavy_base = d_hbase; ra.heavy_cnt = d_hcnt; ra.heavy_len = d_hlen; ra.nheavy = d_scalars + 3;
-      hipLaunchKernelGGL(reverse_light_kernel, dim3(ngroups), dim3(PANN_WAVE), 0, st, ra);
-      PANN_HIP(hipGetLastError());
-      PANN_HIP(hipMemcpyAsync(&nheavy, d_scalars + 3, 4, hipMemcpyDeviceToHost, st));
-      PANN_HIP(hipStreamSynchronize(st));
-    }
-    uint64_t reprune_dc = 0;
-    if (nheavy) {
-      // segments of the heavy vertices: candidates + current row
-      std::vector<uint32_t> h_len(nheavy), h_seg(nheavy);
-      PANN_HIP(hipMemcpy(h_len.data(), d_hlen, (size_t)nheavy * 4, hipMemcpyDeviceToHost));
-      uint64_t tk = 0;
-      uint32_t max_len = 0;
-      for (uint32_t i = 0; i < nheavy; i++) { h_seg[i] = (uint32_t)tk; tk += h_len[i]; max_len = std::max(max_len, h_len[i]); }
-      if (tk >= 0xFFFFFFF0ull) { set_error("vamana insert: re-prune too large"); return PANN_ERR_BAD_ARG; }
-      const size_t stmp2 = seg_sort_temp_bytes((uint32_t)tk, nheavy);
-      uint32_t *h_dseg, *h_dsend, *h_ddc; uint64_t *hk_a, *hk_b; void* h_tmp;
-      auto layout2 = [&](Bump& bb) {
-        h_dseg = bb.take<uint32_t>(nheavy); h_dsend = bb.take<uint32_t>(nheavy); h_ddc = bb.take<uint32_t>(nheavy);
-        hk_a = bb.take<uint64_t>(tk + 1); hk_b = bb.take<uint64_t>(tk + 1); h_tmp = bb.take<uint8_t>(stmp2 + 16);
-      };
-      Bump dry2(nullptr, 0); layout2(dry2);
-      if (int rc = ws2.ensure(dry2.off + 4096)) return rc;
-      Bump b2(ws2.buf, ws2.bytes); layout2(b2);
-      PANN_HIP(hipMemcpyAsync(h_dseg, h_seg.data(), (size_t)nheavy * 4, hipMemcpyHostToDevice, st));
-      PANN_HIP(hipMemsetAsync(h_ddc, 0, (size_t)nheavy * 4, st));
-      PruneArgs pb{};
-      pb.pv = pa.pv; pb.dbytes = ix.dbytes; pb.graph = ix.graph; pb.gstride = ix.gstride; pb.max_deg = ix.max_deg;
-      pb.owners = d_hown; pb.cand_ids = d_src; pb.cand_dists = nullptr; pb.cand_base = d_hbase; pb.cand_cnt = d_hcnt;
-      pb.seg_begin = h_dseg; pb.seg_end = h_dsend; pb.dcmps = h_ddc; pb.add_out_nbrs = 1; pb.m = nheavy;
-      GreedyArgs gb{};
-      gb.pv = pa.pv; gb.dbytes = ix.dbytes; gb.owners = d_hown; gb.alpha = alpha; gb.R = R;
-      gb.rows_out = nullptr; gb.rows_stride = 0; gb.cnt_out = nullptr; gb.graph = ix.graph; gb.gstride = ix.gstride;
-      gb.dcmps = h_ddc; gb.m = nheavy;
-      if (int rc = run_prune(ix, pb, gb, hk_a, hk_b, (uint32_t)tk, h_tmp, stmp2, st, max_len)) return rc;
-      if (stats) {
-        std::vector<uint32_t> hd(nheavy), ho(stats->per_point_dist_cmps ? nheavy : 0);
-        PANN_HIP(hipMemcpyAsync(hd.data(), h_ddc, (size_t)nheavy * 4, hipMemcpyDeviceToHost, st));
-        if (!ho.empty()) PANN_HIP(hipMemcpyAsync(ho.data(), d_hown, (size_t)nheavy * 4, hipMemcpyDeviceToHost, st));
-        PANN_HIP(hipStreamSynchronize(st));
-        for (uint32_t v : hd) reprune_dc += v;
-        for (size_t i = 0; i < ho.size(); i++) stats->per_point_dist_cmps[ho[i]] += hd[i];      // vamana/index.h:298
-      }
-    }
-    PANN_HIP(hipStreamSynchronize(st));
-    const auto t4 = now();
+    const auto t2 = now_();
     if (stats) {
       std::vector<uint32_t> hs(m), hp(m), hv(m);
       PANN_HIP(hipMemcpy(hs.data(), d_dcs, (size_t)m * 4, hipMemcpyDeviceToHost));
@@ -762,12 +689,125 @@ int insert_batch_dev(const DeviceIndex& ix, Workspace& ws, Workspace& ws2, Works
           if (stats->per_point_dist_cmps) stats->per_point_dist_cmps[hb[i]] += hs[i] + hp[i];
         }
       }
-      stats->prune_dist_cmps += reprune_dc;
-      stats->t_search_s += secs(t0, t1); stats->t_prune_s += secs(t1, t2);
-      stats->t_bidirect_s += secs(t2, t3); stats->t_reprune_s += secs(t3, t4);
+      stats->t_search_s += secs_(t0, t1); stats->t_prune_s += secs_(t1, t2);
     }
     return PANN_OK;
   }
+}
+
+int vamana_apply_rows_dev(const DeviceIndex& ix, Workspace& ws, Workspace& ws2, hipStream_t st, const uint32_t* d_batch, uint32_t m,
+                          const uint32_t* d_rows, uint32_t R, double alpha, pann_build_stats* stats) {
+  if (m == 0) return PANN_OK;
+  if (R == 0 || R > ix.max_deg || R > 1024) { set_error("vamana insert: R must be in [1, min(max_deg,1024)]"); return PANN_ERR_BAD_ARG; }
+  const auto t2 = now_();
+  const uint64_t total_edges = (uint64_t)m * R;
+  if (total_edges >= 0xFFFFFFF0ull) { set_error("vamana insert: batch too large"); return PANN_ERR_BAD_ARG; }
+  const size_t stmp = std::max(sort_temp_bytes((uint32_t)total_edges), scan_temp_bytes((uint32_t)total_edges));
+  uint32_t *d_heads, *d_gidx, *d_gstart, *d_src, *d_hown, *d_hcnt, *d_hlen, *d_scalars;
+  uint64_t *ek_a, *ek_b, *d_hbase; void* d_tmp;
+  auto layout = [&](Bump& b) {
+    d_scalars = b.take<uint32_t>(64);   // [1] nvalid, [2] ngroups, [3] nheavy
+    ek_a = b.take<uint64_t>(total_edges + 1); ek_b = b.take<uint64_t>(total_edges + 1);
+    d_heads = b.take<uint32_t>(total_edges + 1); d_gidx = b.take<uint32_t>(total_edges + 1);
+    d_gstart = b.take<uint32_t>(total_edges + 1); d_src = b.take<uint32_t>(total_edges + 1);
+    d_hown = b.take<uint32_t>(total_edges + 1); d_hbase = b.take<uint64_t>(total_edges + 1);
+    d_hcnt = b.take<uint32_t>(total_edges + 1); d_hlen = b.take<uint32_t>(total_edges + 1);
+    d_tmp = b.take<uint8_t>(stmp + 16);
+  };
+  Bump dry(nullptr, 0); layout(dry);
+  if (int rc = ws.ensure(dry.off + 4096)) return rc;
+  Bump b(ws.buf, ws.bytes); layout(b);
+
+  // ---- :268-270 write the new out-neighbourhoods (only now: every search and prune of the batch saw the old graph)
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(m), dim3(PANN_WAVE), 0, st, ix.graph, ix.gstride, d_batch, d_rows, R, m);
+  PANN_HIP(hipGetLastError());
+
+  // ---- 3. reverse edges grouped by target (:278-282) ----
+  const uint32_t te = (uint32_t)total_edges;
+  hipLaunchKernelGGL(edge_keys_kernel, dim3((te + 255) / 256), dim3(256), 0, st, d_rows, R, m, ek_a);
+  size_t tb = stmp;
+  PANN_HIP(rocprim::radix_sort_keys(d_tmp, tb, ek_a, ek_b, te, 0, 64, st));
+  PANN_HIP(hipMemsetAsync(d_scalars, 0, 256, st));
+  hipLaunchKernelGGL(edge_heads_kernel, dim3((te + 255) / 256), dim3(256), 0, st, ek_b, (uint64_t)te, d_heads, d_scalars + 1);
+  tb = stmp;
+  PANN_HIP(rocprim::exclusive_scan(d_tmp, tb, d_heads, d_gidx, 0u, te, rocprim::plus<uint32_t>(), st));
+  hipLaunchKernelGGL(group_starts_kernel, dim3((te + 255) / 256), dim3(256), 0, st, d_heads, d_gidx, (uint64_t)te, d_gstart);
+  uint32_t h_last[2];
+  PANN_HIP(hipMemcpyAsync(&h_last[0], d_gidx + (te - 1), 4, hipMemcpyDeviceToHost, st));
+  PANN_HIP(hipMemcpyAsync(&h_last[1], d_heads + (te - 1), 4, hipMemcpyDeviceToHost, st));
+  PANN_HIP(hipStreamSynchronize(st));
+  const uint32_t ngroups = h_last[0] + h_last[1];
+  PANN_HIP(hipMemcpyAsync(d_scalars + 2, &ngroups, 4, hipMemcpyHostToDevice, st));
+  const auto t3 = now_();
+
+  // ---- 4. append or re-prune per target (:289-300) ----
+  uint32_t nheavy = 0;
+  if (ngroups) {
+    ReverseArgs ra{};
+    ra.graph = ix.graph; ra.gstride = ix.gstride; ra.R = R; ra.ekeys = ek_b; ra.gstart = d_gstart;
+    ra.ngroups = d_scalars + 2; ra.nvalid = d_scalars + 1; ra.batch = d_batch; ra.edge_src = d_src;
+    ra.heavy_owner = d_hown; ra.heavy_base = d_hbase; ra.heavy_cnt = d_hcnt; ra.heavy_len = d_hlen; ra.nheavy = d_scalars + 3;
+    hipLaunchKernelGGL(reverse_light_kernel, dim3(ngroups), dim3(PANN_WAVE), 0, st, ra);
+    PANN_HIP(hipGetLastError());
+    PANN_HIP(hipMemcpyAsync(&nheavy, d_scalars + 3, 4, hipMemcpyDeviceToHost, st));
+    PANN_HIP(hipStreamSynchronize(st));
+  }
+  uint64_t reprune_dc = 0;
+  if (nheavy) {
+    // the heavy vertices were queued through an atomic counter, i.e. in no fixed order; every re-prune reads only its own
+    // vertex's row and candidates, so the graph does not depend on that order
+    std::vector<uint32_t> h_len(nheavy), h_seg(nheavy);
+    PANN_HIP(hipMemcpy(h_len.data(), d_hlen, (size_t)nheavy * 4, hipMemcpyDeviceToHost));
+    uint64_t tk = 0;
+    uint32_t max_len = 0;
+    for (uint32_t i = 0; i < nheavy; i++) { h_seg[i] = (uint32_t)tk; tk += h_len[i]; max_len = std::max(max_len, h_len[i]); }
+    if (tk >= 0xFFFFFFF0ull) { set_error("vamana insert: re-prune too large"); return PANN_ERR_BAD_ARG; }
+    const size_t stmp2 = seg_sort_temp_bytes((uint32_t)tk, nheavy);
+    uint32_t *h_dseg, *h_dsend, *h_ddc; uint64_t *hk_a, *hk_b; void* h_tmp;
+    auto layout2 = [&](Bump& bb) {
+      h_dseg = bb.take<uint32_t>(nheavy); h_dsend = bb.take<uint32_t>(nheavy); h_ddc = bb.take<uint32_t>(nheavy);
+      hk_a = bb.take<uint64_t>(tk + 1); hk_b = bb.take<uint64_t>(tk + 1); h_tmp = bb.take<uint8_t>(stmp2 + 16);
+    };
+    Bump dry2(nullptr, 0); layout2(dry2);
+    if (int rc = ws2.ensure(dry2.off + 4096)) return rc;
+    Bump b2(ws2.buf, ws2.bytes); layout2(b2);
+    PANN_HIP(hipMemcpyAsync(h_dseg, h_seg.data(), (size_t)nheavy * 4, hipMemcpyHostToDevice, st));
+    PANN_HIP(hipMemsetAsync(h_ddc, 0, (size_t)nheavy * 4, st));
+    PruneArgs pb{};
+    pb.pv = PointsView{ix.points, ix.pstride, ix.nch, ix.exact}; pb.dbytes = ix.dbytes; pb.graph = ix.graph; pb.gstride = ix.gstride; pb.max_deg = ix.max_deg;
+    pb.owners = d_hown; pb.cand_ids = d_src; pb.cand_dists = nullptr; pb.cand_base = d_hbase; pb.cand_cnt = d_hcnt;
+    pb.seg_begin = h_dseg; pb.seg_end = h_dsend; pb.dcmps = h_ddc; pb.add_out_nbrs = 1; pb.m = nheavy;
+    GreedyArgs gb{};
+    gb.pv = pb.pv; gb.dbytes = ix.dbytes; gb.owners = d_hown; gb.alpha = alpha; gb.R = R;
+    gb.rows_out = nullptr; gb.rows_stride = 0; gb.cnt_out = nullptr; gb.graph = ix.graph; gb.gstride = ix.gstride;
+    gb.dcmps = h_ddc; gb.m = nheavy;
+    if (int rc = run_prune(ix, pb, gb, hk_a, hk_b, (uint32_t)tk, h_tmp, stmp2, st, max_len)) return rc;
+    if (stats) {
+      std::vector<uint32_t> hd(nheavy), ho(stats->per_point_dist_cmps ? nheavy : 0);
+      PANN_HIP(hipMemcpyAsync(hd.data(), h_ddc, (size_t)nheavy * 4, hipMemcpyDeviceToHost, st));
+      if (!ho.empty()) PANN_HIP(hipMemcpyAsync(ho.data(), d_hown, (size_t)nheavy * 4, hipMemcpyDeviceToHost, st));
+      PANN_HIP(hipStreamSynchronize(st));
+      for (uint32_t v : hd) reprune_dc += v;
+      for (size_t i = 0; i < ho.size(); i++) stats->per_point_dist_cmps[ho[i]] += hd[i];      // vamana/index.h:298
+    }
+  }
+  PANN_HIP(hipStreamSynchronize(st));
+  const auto t4 = now_();
+  if (stats) {
+    stats->prune_dist_cmps += reprune_dc;
+    stats->t_bidirect_s += secs_(t2, t3); stats->t_reprune_s += secs_(t3, t4);
+  }
+  return PANN_OK;
+}
+
+int insert_batch_dev(const DeviceIndex& ix, Workspace& ws, Workspace& ws2, Workspace& search_ws, Workspace& rows_ws, hipStream_t st,
+                     const uint32_t* d_batch, uint32_t m, uint32_t start, uint32_t R, uint32_t L, double alpha,
+                     uint32_t* vcap_io, pann_build_stats* stats) {
+  if (m == 0) return PANN_OK;
+  if (int rc = rows_ws.ensure((size_t)m * R * 4 + 256)) return rc;
+  uint32_t* d_rows = (uint32_t*)rows_ws.buf;
+  if (int rc = vamana_search_prune_dev(ix, ws, search_ws, st, d_batch, m, start, R, L, alpha, vcap_io, d_rows, stats)) return rc;
+  return vamana_apply_rows_dev(ix, ws, ws2, st, d_batch, m, d_rows, R, alpha, stats);
 }
 
 int sort_neighbors_dev(const DeviceIndex& ix, hipStream_t st) {

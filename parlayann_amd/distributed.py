@@ -6,7 +6,10 @@ translates reference code.
     and a max-reduce of the elapsed time (`timed_steps`).
   * sharded index (C4)                 : every rank searches ALL queries on its own id range; one
     all-gather of the per-rank top-k (k*8 B per query per rank) and a merge by (dist,id).
-  * sharded build stitch               : ONE all-gather of the adjacency rows (n/W x (R+1) x 4 B per rank).
+  * sharded Vamana build               : points and graph replicated, every BATCH of batch_insert split over the ranks;
+    ONE all-gather of the batch's new adjacency rows (m x R x 4 B) per batch stitches the replicas back together
+    (`vamana_build_sharded`).  The graph is bit-identical to the single-GPU build.
+  * sharded build stitch (primitive)   : ONE all-gather of adjacency rows (n/W x (R+1) x 4 B per rank).
 """
 import time
 
@@ -45,16 +48,33 @@ def timed_steps(step, steps, warmup, sync=lambda: None, device=None):
 
 
 def merge_topk(ids, dists, k):
-    """ids/dists: [W, nq, k] per-shard results with GLOBAL ids -> [nq, k] smallest by (dist, id)."""
-    ids = np.asarray(ids); dists = np.asarray(dists)
+    """ids/dists: [W, nq, k] per-shard results with GLOBAL ids -> [nq, k] smallest by (dist, id).  Host (numpy) form,
+    the checker of the device kernel `pann_merge_topk_dev` and the merge of the CPU tests; the product path
+    (`DeviceShardedIndex`) merges on the GPU."""
+    ids = np.asarray(ids, dtype=np.uint32); dists = np.asarray(dists, dtype=np.float32)
     W, nq, kk = ids.shape
     allid = np.transpose(ids, (1, 0, 2)).reshape(nq, W * kk)
     alld = np.transpose(dists, (1, 0, 2)).reshape(nq, W * kk)
-    out_i = np.empty((nq, k), np.uint32); out_d = np.empty((nq, k), np.float32)
-    for i in range(nq):
-        order = np.lexsort((allid[i], alld[i]))[:k]
-        out_i[i] = allid[i][order]; out_d[i] = alld[i][order]
-    return out_i, out_d
+    # one integer key per pair that orders like (dist, id): the float's bits made monotone, then the id
+    u = (alld + np.float32(0.0)).view(np.uint32).astype(np.uint64)
+    ordd = np.where(u & 0x80000000, u ^ 0xFFFFFFFF, u ^ 0x80000000)
+    key = (ordd << np.uint64(32)) | allid.astype(np.uint64)
+    key[allid == 0xFFFFFFFF] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    order = np.argsort(key, axis=1, kind="stable")[:, :k]
+    return np.take_along_axis(allid, order, 1), np.take_along_axis(alld, order, 1)
+
+
+def all_gather_tensor(t):
+    """ONE all-gather of equally shaped tensors -> [W, *t.shape] on t's device.  Under nccl (= RCCL) device tensors go
+    GPU to GPU; under gloo (CPU tests, rehearsals of several ranks on one GPU) a device tensor is staged through the host."""
+    rank, world = _world()
+    if world == 1:
+        return t.unsqueeze(0)
+    staged = t.is_cuda and dist.get_backend() != "nccl"
+    src = (t.cpu() if staged else t).contiguous()
+    out = torch.empty((world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(out, src)
+    return out.to(t.device) if staged else out
 
 
 def all_gather_array(a, device=None):
@@ -94,6 +114,50 @@ class ShardedIndex:
         return merge_topk(ids, dists, k)
 
 
+class DeviceShardedIndex:
+    """The sharded index on the product path, nothing on the host between the kernels: rank r holds base points
+    [lo, hi) as a DeviceIndex with its own sub-graph (local ids); a query batch (a device tensor, the same on every rank)
+    is searched on every shard (pann_batch_search_dev), the local ids get the shard base added, ONE all-gather moves
+    every rank's [nq, k] ids and distances (k * 8 bytes per query per rank) and pann_merge_topk_dev keeps the k smallest
+    by (dist, id).  Results stay in HBM (torch tensors)."""
+
+    def __init__(self, points, max_degree, build, device_ordinal=0, metric="Euclidian"):
+        from .index import DeviceIndex
+        self.rank, self.world = _world()
+        self.n = len(points)
+        self.lo, self.hi = shard_range(self.n, self.rank, self.world)
+        self.ix = DeviceIndex(points[self.lo:self.hi], max_degree=max_degree, device=device_ordinal, metric=metric)
+        build(self.ix)
+        self.dev = torch.device("cuda", device_ordinal)
+        self._starts = torch.zeros(1, dtype=torch.int32, device=self.dev)
+
+    def search(self, d_queries, k, beam, cut=1.35):
+        """d_queries: [nq, row bytes] uint8 device tensor (raw rows of the index dtype).  Returns (ids, dists) device tensors
+        [nq, k] (int32 holding uint32 ids, float32)."""
+        import ctypes as C
+        from ._capi import QueryParams, SearchOut, check
+        lib = self.ix._lib
+        nq = d_queries.shape[0]
+        ids = torch.empty((nq, k), dtype=torch.int32, device=self.dev)
+        dists = torch.empty((nq, k), dtype=torch.float32, device=self.dev)
+        qp = QueryParams(k=k, beam=beam, cut=cut, limit=self.ix.n, degree_limit=self.ix.max_degree, rerank_factor=100, pad=1.0)
+        out = SearchOut(ids=ids.data_ptr(), dists=dists.data_ptr(), out_k=k)
+        st = torch.cuda.current_stream(self.dev)
+        check(lib.pann_batch_search_dev(self.ix.handle, d_queries.data_ptr(), None, nq, d_queries.shape[1], self._starts.data_ptr(), 1,
+                                        C.byref(qp), C.byref(out), C.c_void_p(st.cuda_stream)))
+        gids = torch.where(ids == -1, ids, ids + self.lo)                   # -1 == 0xFFFFFFFF: unused slot of a short list
+        all_i = all_gather_tensor(gids)                                     # [W, nq, k]
+        all_d = all_gather_tensor(dists)
+        oi = torch.empty((nq, k), dtype=torch.int32, device=self.dev)
+        od = torch.empty((nq, k), dtype=torch.float32, device=self.dev)
+        check(lib.pann_merge_topk_dev(all_i.data_ptr(), all_d.data_ptr(), all_i.shape[0], nq, k, k, oi.data_ptr(), od.data_ptr(),
+                                      C.c_void_p(st.cuda_stream)))
+        return oi, od
+
+    def close(self):
+        self.ix.close()
+
+
 def stitch_graph(local_rows, n, device=None):
     """ONE all-gather of adjacency rows: local_rows is this rank's [per, R+1] slab (reference row
     layout, ids already global), padded to the common shard height; returns the full [n, R+1] graph."""
@@ -126,3 +190,126 @@ def hcnng_build_tree_parallel(build_tree, n, num_clusters, mst_deg, device=None)
             out[sel, 1 + out[sel, 0].astype(np.int64)] = g[sel, 1 + j]
             out[sel, 0] += 1
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Sharded Vamana build (vamana/index.h:188-316 is what the ranks run between the collectives)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def build_schedule(n, seed):
+    """(permutation [n] uint32, batch bounds [(floor, ceiling), ...]) of one pass of build_index -- from libpann.so's
+    host-only helpers, so every rank (and the single-GPU pann_vamana_build) derives the same schedule."""
+    import ctypes as C
+    from . import _capi
+    lib = _capi.load()
+    perm = np.empty(n, np.uint32)
+    lib.pann_build_permutation(n, seed, perm.ctypes.data_as(C.c_void_p))
+    nb = int(lib.pann_vamana_batch_schedule(n, n, None, 0))
+    bounds = np.zeros((nb, 2), np.uint64)
+    lib.pann_vamana_batch_schedule(n, n, bounds.ctypes.data_as(C.c_void_p), nb)
+    return perm, [(int(a), int(b)) for a, b in bounds]
+
+
+def _world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def all_gather_rows(local, per):
+    """ONE all-gather of equally sized row blocks: `local` is this rank's [<=per, R] int32 tensor (a device tensor on the
+    product path), padded here to [per, R]; returns [W * per, R] on the same device."""
+    R = local.shape[1]
+    if local.shape[0] < per:
+        pad = torch.full((per - local.shape[0], R), -1, dtype=local.dtype, device=local.device)
+        local = torch.cat([local, pad], 0)
+    return all_gather_tensor(local).reshape(-1, R)
+
+
+def vamana_build_sharded(n, R, L, alpha, num_passes, seed, phase_a, phase_b, finish=None, device="cpu", min_split=None):
+    """build_index (vamana/index.h:150-186) with every batch of batch_insert (:223-300) split over the ranks.
+
+    Every rank holds ALL points and a replica of the graph.  Per batch (m ids of the shared insertion order):
+      1. rank r runs `phase_a(ids[r*per : (r+1)*per])` -> rows [., R] (beam search + robustPrune, :247-266: reads the graph only)
+      2. ONE all-gather of the rows (m x R x 4 bytes over all ranks; C3: 200 000 x 64 x 4 = 51 MB per batch, 134 batches)
+      3. every rank runs `phase_b(ids, rows)` for the whole batch (:268-300: deterministic), so the replicas stay identical
+    Batches of fewer than `min_split` points (the first prefix-doubling batches) are run whole by every rank, without a
+    collective.  The result equals the single-GPU build bit for bit (phase A of a point does not depend on who runs it).
+
+    phase_a(ids: int32 tensor on `device`, alpha) -> int32 tensor [len(ids), R] on `device` (unused slots -1 == 0xFFFFFFFF)
+    phase_b(ids, rows, alpha); finish() = the final neighbour sort (:180-185), run by every rank.
+    Returns {"collectives": count, "bytes_gathered": total bytes received per rank}."""
+    rank, world = _world()
+    if min_split is None:
+        min_split = 64 * world
+    perm, bounds = build_schedule(n, seed)
+    d_perm = torch.from_numpy(perm.view(np.int32)).to(device)
+    info = {"collectives": 0, "bytes_gathered": 0}
+    for p in range(num_passes):
+        a = alpha if p == num_passes - 1 else 1.0                      # :173-178
+        for lo, hi in bounds:
+            ids = d_perm[lo:hi]
+            m = hi - lo
+            if world == 1 or m < min_split:
+                rows = phase_a(ids, a)
+            else:
+                per = (m + world - 1) // world
+                s0, s1 = min(m, rank * per), min(m, (rank + 1) * per)
+                mine = phase_a(ids[s0:s1], a) if s1 > s0 else torch.empty((0, R), dtype=torch.int32, device=device)
+                rows = all_gather_rows(mine, per)[:m]
+                info["collectives"] += 1
+                info["bytes_gathered"] += world * per * R * 4
+            phase_b(ids, rows, a)
+    if finish is not None:
+        finish()
+    return info
+
+
+def device_vamana_build_sharded(ix, R, L, alpha, num_passes=1, seed=1, sort_neighbors=True, min_split=None):
+    """`vamana_build_sharded` on a DeviceIndex (replicated on every rank's GPU): the phases are the C-ABI's
+    pann_vamana_search_prune_dev / pann_vamana_apply_rows_dev on torch device tensors, the collective is RCCL's."""
+    dev = torch.device("cuda", ix._lib.pann_index_device(ix._h))
+    stats = _new_build_stats()
+
+    def phase_a(ids, a):
+        ids = ids.contiguous()
+        rows = torch.empty((ids.numel(), R), dtype=torch.int32, device=dev)
+        ix.vamana_search_prune_dev(ids.data_ptr(), ids.numel(), R, L, a, rows.data_ptr(), stats=stats)
+        return rows
+
+    def phase_b(ids, rows, a):
+        ids = ids.contiguous(); rows = rows.contiguous()
+        torch.cuda.current_stream(dev).synchronize()      # the gathered rows were produced on torch's streams; the library runs on its own
+        ix.vamana_apply_rows_dev(ids.data_ptr(), ids.numel(), rows.data_ptr(), R, a, stats=stats)
+
+    info = vamana_build_sharded(ix.n, R, L, alpha, num_passes, seed, phase_a, phase_b,
+                                finish=ix.vamana_sort_neighbors if sort_neighbors else None, device=dev, min_split=min_split)
+    info["stats"] = stats
+    return info
+
+
+def _new_build_stats():
+    from ._capi import BuildStats
+    return BuildStats()
+
+
+def device_hcnng_build_tree_parallel(ix, num_clusters, cluster_size, mst_deg, seed=1):
+    """HCNNG with the trees split over the ranks on ONE resident DeviceIndex per rank (all points, graph replica): rank r builds
+    trees r, r + W, ... into a device slab (pann_hcnng_build_trees_dev), ONE all-gather of the slabs (n x ceil(T/W) x mst_deg x 4
+    bytes per rank), every rank interleaves them in tree order into its graph (pann_hcnng_assemble_dev) -- the single-GPU
+    graph, bit for bit.  Returns the seconds {tree, leaf kNN, MST} this rank spent."""
+    import ctypes as C
+    from ._capi import check
+    rank, world = _world()
+    dev = torch.device("cuda", ix._lib.pann_index_device(ix._h))
+    per = (num_clusters + world - 1) // world
+    mine = len(range(rank, num_clusters, world))
+    stride = per * mst_deg
+    slab = torch.empty((ix.n, stride), dtype=torch.int32, device=dev)
+    times = np.zeros(3, np.float64)
+    check(ix._lib.pann_hcnng_build_trees_dev(ix._h, rank, world, mine, cluster_size, mst_deg, seed, C.c_void_p(slab.data_ptr()), stride,
+                                             times.ctypes.data_as(C.c_void_p)))
+    slabs = all_gather_tensor(slab)                                          # [W, n, stride]
+    torch.cuda.current_stream(dev).synchronize()          # the library's stream does not order itself behind torch's
+    check(ix._lib.pann_hcnng_assemble_dev(ix._h, C.c_void_p(slabs.data_ptr()), slabs.shape[0], stride, num_clusters, mst_deg))
+    return {"tree_s": times[0], "leaf_knn_s": times[1], "mst_s": times[2], "bytes_gathered": int(slabs.numel()) * 4}

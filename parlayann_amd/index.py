@@ -176,6 +176,24 @@ class DeviceIndex:
                                           C.byref(st)))
         return st
 
+    # ---- the two phases of a batch on device pointers (multi-GPU build, parlayann_amd/distributed.py) ----
+    def vamana_search_prune_dev(self, d_batch_ptr, m, R, L, alpha, d_rows_ptr, start=0, stats=None):
+        """phase A (vamana/index.h:247-266) for m batch ids at device address d_batch_ptr -> rows [m, R] at d_rows_ptr"""
+        st = BuildStats() if stats is None else stats
+        check(self._lib.pann_vamana_search_prune_dev(self._h, C.c_void_p(d_batch_ptr), m, start, R, L, float(alpha),
+                                                     C.c_void_p(d_rows_ptr), C.byref(st)))
+        return st
+
+    def vamana_apply_rows_dev(self, d_batch_ptr, m, d_rows_ptr, R, alpha, stats=None):
+        """phase B (vamana/index.h:268-300) for the whole batch: rows [m, R] at device address d_rows_ptr"""
+        st = BuildStats() if stats is None else stats
+        check(self._lib.pann_vamana_apply_rows_dev(self._h, C.c_void_p(d_batch_ptr), m, C.c_void_p(d_rows_ptr), R, float(alpha),
+                                                   C.byref(st)))
+        return st
+
+    def vamana_sort_neighbors(self):
+        check(self._lib.pann_vamana_sort_neighbors(self._h))
+
     # ---- distances / dense all-pairs ----
     def hcnng_build(self, num_clusters, cluster_size, mst_deg, seed=1):
         """hcnng_index.h:273-281 on the device (trees, leaf kNN, Kruskal); returns {tree_s, leaf_knn_s, mst_s}."""

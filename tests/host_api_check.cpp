@@ -148,7 +148,8 @@ int main(int argc, char** argv) {
     parlay::sequence<indexType> none;
     G2[0].update_neighbors(none);
     stats<indexType> QS3(Query_Points.size());
-    auto cut = qsearchAll<PR, PR, PR, indexType>(Query_Points, Query_Points, Query_Points, G2, Points, Points, Points, QS3, (indexType)0, QP);
+    QueryParams q3 = QP;      // searchAll: qsearchAll aborts when fewer than k vertices are reachable (beamSearch.h:416-419)
+    auto cut = searchAll<PR, indexType>(Query_Points, G2, Points, QS3, (indexType)0, q3);
     dump("isolated_start_ids", flat(cut));
 
     // ---- batch_insert(inserts, G, Points, QPoints, BuildStats, alpha, random_order, base, max_fraction, print)   :188-192 ----

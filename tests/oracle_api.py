@@ -126,6 +126,41 @@ class Oracle:
         assert rc == 0
         return stats
 
+    def vamana_phase_a(self, points, graph, batch, R, L, alpha, start=0, metric="l2", threads=None):
+        """vamana/index.h:247-266 for the batch points given; returns rows [m, R], unused slots 0xFFFFFFFF"""
+        points = np.ascontiguousarray(points)
+        n, d = points.shape
+        batch = np.ascontiguousarray(batch, dtype=np.uint32)
+        rows = np.empty((len(batch), R), np.uint32)
+        rc = self.lib.pann_oracle_vamana_phase_a(
+            _p(points), C.c_uint64(n), C.c_uint32(d), C.c_int(DT[points.dtype]), C.c_uint64(points.strides[0]),
+            C.c_int(_m(metric)), _p(graph), C.c_uint32(graph.shape[1] - 1), _p(batch), C.c_uint64(len(batch)),
+            C.c_uint32(start), C.c_uint32(R), C.c_uint32(L), C.c_double(alpha), _p(rows), None, C.c_int(threads or self.threads))
+        assert rc == 0
+        return rows
+
+    def vamana_phase_b(self, points, graph, batch, rows, R, alpha, metric="l2", threads=None):
+        """vamana/index.h:268-300 for the whole batch, in place on `graph`"""
+        points = np.ascontiguousarray(points)
+        assert graph.dtype == np.uint32 and graph.flags.c_contiguous
+        n, d = points.shape
+        batch = np.ascontiguousarray(batch, dtype=np.uint32); rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        rc = self.lib.pann_oracle_vamana_phase_b(
+            _p(points), C.c_uint64(n), C.c_uint32(d), C.c_int(DT[points.dtype]), C.c_uint64(points.strides[0]),
+            C.c_int(_m(metric)), _p(graph), C.c_uint32(graph.shape[1] - 1), _p(batch), C.c_uint64(len(batch)), _p(rows),
+            C.c_uint32(R), C.c_double(alpha), None, C.c_int(threads or self.threads))
+        assert rc == 0
+
+    def sort_neighbors(self, points, graph, metric="l2"):
+        """vamana/index.h:180-185 (ties by id), in place: a zero-pass build with the final sort"""
+        points = np.ascontiguousarray(points)
+        n, d = points.shape
+        rc = self.lib.pann_oracle_vamana_build(
+            _p(points), C.c_uint64(n), C.c_uint32(d), C.c_int(DT[points.dtype]), C.c_uint64(points.strides[0]),
+            C.c_int(_m(metric)), _p(graph), C.c_uint32(graph.shape[1] - 1), C.c_uint32(graph.shape[1] - 1), C.c_uint32(1),
+            C.c_double(1.0), C.c_int(0), C.c_uint64(0), C.c_int(1), None, C.c_int(self.threads))
+        assert rc == 0
+
     def vamana_build(self, points, R, L, alpha, num_passes=1, seed=1, sort_neighbors=True, metric="l2",
                      max_degree=None, threads=None, point_stats=None):
         """point_stats: optional (visited[n], dists[n]) uint32 arrays, accumulated like the reference's BuildStats"""

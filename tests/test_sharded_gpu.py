@@ -1,6 +1,11 @@
-"""Sharded index on the GPU box: 2 processes (gloo rendezvous, both using the one visible GPU for
-compute), each builds + searches its id range with the product's DeviceIndex; the all-gathered,
-merged top-k must equal the single-process merge of the same per-shard device results."""
+"""The multi-GPU paths on the GPU box with the PRODUCT's device code on every rank: 2 processes (gloo rendezvous, both
+computing on the one visible GPU -- RCCL cannot put two ranks on one device; under gloo the collectives' device tensors are
+staged through the host, under nccl they are not).  Every expectation comes from the ORACLE, not from the device code:
+
+  * sharded index (C4 shape): merged top-k of the two shards == per-shard oracle searches merged by (dist, id), bit for bit
+  * sharded Vamana build (one all-gather of the batch's rows per batch) == the oracle's single-process build, bit for bit
+  * tree-parallel HCNNG on ONE resident DeviceIndex per rank == the oracle's single-process build, bit for bit
+"""
 import os
 import sys
 
@@ -10,60 +15,122 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def _build(shard):
-    from parlayann_amd import DeviceIndex
-    ix = DeviceIndex(shard, max_degree=32)
-    ix.vamana_build(32, 64, 1.2, num_passes=1, seed=3)
-    return ix
-
-
-def _search(ix, queries, k, beam):
-    r = ix.batch_search(queries, k=k, beam=beam)
-    return r["ids"], r["dists"]
+N, D_, NQ = 20000, 128, 400
 
 
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
     import torch.distributed as dist
-    from parlayann_amd import datasets, distributed as D
+    from parlayann_amd import DeviceIndex, datasets, distributed as D
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    X = datasets.sift_like(20000, 128, seed=1, dtype=np.float16)
-    Q = datasets.sift_like(200, 128, seed=2, dtype=np.float16)
-    sh = D.ShardedIndex(X, _build, _search)
-    ids, dists = sh.search(Q, 10, 64)
-    q.put((rank, ids, dists))
+    X = datasets.sift_like(N, D_, seed=1, dtype=np.float16)          # integer-valued: fp16 distances exact in any order
+    Q = datasets.sift_like(NQ, D_, seed=2, dtype=np.float16)
+    # ---- sharded index: every shard built and searched on the device, ids/dists merged on the device ----
+    sh = D.DeviceShardedIndex(X, 32, lambda ix: ix.vamana_build(32, 64, 1.2, num_passes=1, seed=3))
+    d_q = torch.from_numpy(Q.view(np.uint8).reshape(NQ, -1)).to(sh.dev)
+    oi, od = sh.search(d_q, 10, 64)
+    torch.cuda.synchronize()
+    ids, dists = oi.cpu().numpy().view(np.uint32), od.cpu().numpy()
+    sh.close()
+    # ---- sharded Vamana build: points + graph replicated, every batch split over the ranks ----
+    Xb = X[:8000]
+    ix = DeviceIndex(Xb, max_degree=32)
+    info = D.device_vamana_build_sharded(ix, 32, 64, 1.2, num_passes=2, seed=5, min_split=16)
+    Gv = ix.get_graph()
+    ix.close()
+    # ---- tree-parallel HCNNG on one resident index per rank ----
+    Xh = datasets.sift_like(6000, 64, seed=7, dtype=np.uint8)
+    ih = DeviceIndex(Xh, max_degree=15)
+    D.device_hcnng_build_tree_parallel(ih, 5, 300, 3, seed=11)
+    Gh = ih.get_graph()
+    ih.close()
+    q.put((rank, ids, dists, Gv, info["collectives"], info["bytes_gathered"], Gh))
     dist.barrier()
-    sh.state.close()
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_index(oracle):
-    from parlayann_amd import datasets, distributed as D
+@pytest.fixture(scope="module")
+def two_ranks():
     world, port = 2, 29600 + (os.getpid() % 2000)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    X = datasets.sift_like(20000, 128, seed=1, dtype=np.float16)
-    Q = datasets.sift_like(200, 128, seed=2, dtype=np.float16)
+    return res
+
+
+def test_sharded_index_equals_per_shard_oracle_merged(two_ranks, oracle):
+    from parlayann_amd import datasets, distributed as D
+    X = datasets.sift_like(N, D_, seed=1, dtype=np.float16)
+    Q = datasets.sift_like(NQ, D_, seed=2, dtype=np.float16)
     per_i, per_d = [], []
-    for r in range(world):
-        lo, hi = D.shard_range(len(X), r, world)
-        ix = _build(X[lo:hi])
-        i, d = _search(ix, Q, 10, 64)
-        ix.close()
-        per_i.append(i + np.uint32(lo)); per_d.append(d)
+    for r in range(2):
+        lo, hi = D.shard_range(N, r, 2)
+        G, _ = oracle.vamana_build(X[lo:hi], 32, 64, 1.2, num_passes=1, seed=3)
+        rr = oracle.batch_search(X[lo:hi], G, queries=Q, k=10, beam=64)
+        per_i.append(rr["ids"] + np.uint32(lo)); per_d.append(rr["dists"])
     exp_i, exp_d = D.merge_topk(np.stack(per_i), np.stack(per_d), 10)
-    for r in range(world):
-        np.testing.assert_array_equal(res[r][1], exp_i)
-        np.testing.assert_array_equal(res[r][2], exp_d)
+    for r in range(2):
+        np.testing.assert_array_equal(two_ranks[r][1], exp_i)
+        np.testing.assert_array_equal(two_ranks[r][2], exp_d)
+    # Recall bar.  Round 1 asserted an absolute 0.97, measured 0.968 and lowered the bar to 0.94.  An absolute bar says
+    # nothing about the sharding; what sharding must not do is LOSE recall against one graph over all points searched
+    # with the same beam (every shard gets the full beam, so it should gain).  Both numbers from the oracle:
     gt, gd = oracle.bruteforce_knn(X, Q, 50)
-    assert oracle.recall(exp_i, gt, gd, 10) > 0.94
+    Gall, _ = oracle.vamana_build(X, 32, 64, 1.2, num_passes=1, seed=3)
+    r_single = oracle.recall(oracle.batch_search(X, Gall, queries=Q, k=10, beam=64)["ids"], gt, gd, 10)
+    r_sharded = oracle.recall(exp_i, gt, gd, 10)
+    assert r_sharded >= r_single - 0.001 and r_sharded > 0.95, (r_sharded, r_single)
+
+
+def test_sharded_vamana_build_equals_oracle_single_process_build(two_ranks, oracle):
+    from parlayann_amd import datasets, distributed as D
+    X = datasets.sift_like(N, D_, seed=1, dtype=np.float16)[:8000]
+    Q = datasets.sift_like(NQ, D_, seed=2, dtype=np.float16)
+    Gs, _ = oracle.vamana_build(X, 32, 64, 1.2, num_passes=2, seed=5)
+    cols = np.arange(32)[None, :]
+    for r in range(2):
+        G = two_ranks[r][3]
+        np.testing.assert_array_equal(G[:, 0], Gs[:, 0])
+        np.testing.assert_array_equal(np.where(cols < G[:, :1], G[:, 1:], 0), np.where(cols < Gs[:, :1], Gs[:, 1:], 0))
+    _, bounds = D.build_schedule(len(X), 5)
+    big = [(a, b) for a, b in bounds if b - a >= 16]
+    assert two_ranks[0][4] == 2 * len(big) and two_ranks[0][5] == 2 * sum(2 * ((b - a + 1) // 2) * 32 * 4 for a, b in big)
+    gt, gd = oracle.bruteforce_knn(X, Q, 50)
+    assert oracle.recall(oracle.batch_search(X, Gs, queries=Q, k=10, beam=64)["ids"], gt, gd, 10) > 0.97
+
+
+def test_tree_parallel_hcnng_on_resident_index_equals_oracle(two_ranks, oracle):
+    from parlayann_amd import datasets
+    Xh = datasets.sift_like(6000, 64, seed=7, dtype=np.uint8)
+    Gh = oracle.hcnng_build(Xh, 5, 300, 3, seed=11)
+    for r in range(2):
+        np.testing.assert_array_equal(two_ranks[r][6], Gh)
+
+
+def test_merge_topk_kernel_against_numpy(oracle):
+    import ctypes as C
+    import torch
+    from parlayann_amd import _capi, distributed as D
+    lib = _capi.load()
+    rng = np.random.default_rng(5)
+    for W, nq, k in ((2, 300, 10), (8, 1000, 100), (3, 7, 1)):
+        ids = rng.integers(0, 1 << 31, (W, nq, k)).astype(np.uint32)
+        d = np.sort(rng.integers(0, 50, (W, nq, k)).astype(np.float32), axis=2)       # many ties: the id decides
+        ids[0, ::5, k - 1] = 0xFFFFFFFF; d[0, ::5, k - 1] = np.inf                     # short lists
+        dev = torch.device("cuda", 0)
+        ti = torch.from_numpy(ids.view(np.int32)).to(dev); td = torch.from_numpy(d).to(dev)
+        oi = torch.empty((nq, k), dtype=torch.int32, device=dev); od = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        _capi.check(lib.pann_merge_topk_dev(ti.data_ptr(), td.data_ptr(), W, nq, k, k, oi.data_ptr(), od.data_ptr(),
+                                            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        torch.cuda.synchronize()
+        ei, ed = D.merge_topk(ids, d, k)
+        np.testing.assert_array_equal(oi.cpu().numpy().view(np.uint32), ei)
+        np.testing.assert_array_equal(od.cpu().numpy(), ed)
