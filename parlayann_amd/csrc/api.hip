@@ -656,7 +656,10 @@ int pann_leaf_knn_batch(pann_index* idx, const uint32_t* ids, const uint64_t* le
   PANN_HIP(hipMemcpyAsync(idx->stage[3].p, leaf_offsets, (nleaves + 1) * 8, hipMemcpyHostToDevice, st));
   PANN_HIP(hipMemcpyAsync(idx->stage[4].p, tseg.data(), nt * 4, hipMemcpyHostToDevice, st));
   PANN_HIP(hipMemcpyAsync(idx->stage[5].p, ta0.data(), nt * 4, hipMemcpyHostToDevice, st));
-  if (int rc = dense_topk_dev(idx->ix, idx->ws2, st, nullptr, 0, idx->stage[2].as<uint32_t>(), idx->stage[2].as<uint32_t>(),
+  if (leaf_knn_rows_eligible(idx->ix, m)) {     // one-byte element types: lane-owns-row kernel (leaf_knn.hip)
+    if (int rc = leaf_knn_rows_dev(idx->ix, idx->ws2, st, idx->stage[2].as<uint32_t>(), idx->stage[3].as<uint64_t>(), leaf_offsets, nleaves, m, 1,
+                                   idx->stage[6].as<uint32_t>(), idx->stage[7].as<float>())) return rc;
+  } else if (int rc = dense_topk_dev(idx->ix, idx->ws2, st, nullptr, 0, idx->stage[2].as<uint32_t>(), idx->stage[2].as<uint32_t>(),
                               idx->stage[3].as<uint64_t>(), idx->stage[3].as<uint64_t>(), idx->stage[4].as<uint32_t>(),
                               idx->stage[5].as<uint32_t>(), (uint32_t)nt, total, total, 1, m, 1,
                               idx->stage[6].as<uint32_t>(), idx->stage[7].as<float>())) return rc;

@@ -81,6 +81,7 @@ struct BSParams {
   uint32_t* hash_global;   // [slots][1<<bits] when the filter does not fit LDS
   uint32_t prio_start;     // first block index that runs with raised issue priority (register-frontier beam-64 kernel)
   uint32_t hsplit;         // beam 65..128 in HBM mode: 0 whole table in HBM, 1 half, 2 three quarters of it in LDS
+  uint32_t p24;            // ... whose LDS part holds planar 24-bit entries (n < 2^24 - 1)
   uint64_t* dropped; uint32_t dcap;  // [nq][dcap] visited entries that left a non-full frontier
   uint32_t* work_counter;  // persistent variant: next query to take
   uint32_t* status;        // [0] |= 1 on visited-list overflow, |= 2 on dropped-list overflow
@@ -129,14 +130,42 @@ __device__ __forceinline__ uint32_t lower_bound_lds(const uint64_t* A, uint32_t 
 __device__ __forceinline__ uint32_t split_lds_index(uint32_t s, uint32_t hb) {
   return hb == 1 ? (s >> 1) : (s >> 2) * 3 + (s & 3);
 }
+// Planar 24-bit entries (p24 != 0: n < 2^24 - 1, the LDS part only): a low plane of uint16 followed by a high plane of uint8,
+// 3 bytes per slot instead of 4 -- exact (an id IS 24 bits), and 2 KB less LDS per query at beam 65..128.
+struct LdsPart { uint8_t* base; uint32_t nslots; uint32_t p24; };
+__device__ __forceinline__ uint32_t lds_part_load(const LdsPart& L, uint32_t i) {
+  if (L.p24) {
+    const uint32_t lo = reinterpret_cast<const uint16_t*>(L.base)[i];
+    const uint32_t hi = (L.base + 2 * L.nslots)[i];
+    return lo | (hi << 16);                                              // empty slot = 0xFFFFFF, never equal to an id
+  }
+  return reinterpret_cast<const uint32_t*>(L.base)[i];
+}
+__device__ __forceinline__ void lds_part_store(const LdsPart& L, uint32_t i, uint32_t a) {
+  if (L.p24) {
+    reinterpret_cast<uint16_t*>(L.base)[i] = (uint16_t)a;
+    (L.base + 2 * L.nslots)[i] = (uint8_t)(a >> 16);
+  } else {
+    reinterpret_cast<uint32_t*>(L.base)[i] = a;
+  }
+}
+__device__ __forceinline__ void lds_part_clear(const LdsPart& L, int lane) {
+  if (L.p24) {      // 3 * nslots bytes of 0xFF, nslots a multiple of 64
+    uint32_t* w = reinterpret_cast<uint32_t*>(L.base);
+    for (uint32_t i = lane; i < (3 * L.nslots) / 4; i += PANN_WAVE) w[i] = 0xFFFFFFFFu;
+  } else {
+    uint32_t* w = reinterpret_cast<uint32_t*>(L.base);
+    for (uint32_t i = lane; i < L.nslots; i += PANN_WAVE) w[i] = SENTINEL;
+  }
+}
+
 template <bool HASH_LDS>
 __device__ __forceinline__ bool filter_update(uint32_t* H, uint32_t hmask, bool active, uint32_t a, int lane,
-                                              uint8_t* T = nullptr, uint32_t hb = 0) {
+                                              uint8_t* T = nullptr, uint32_t hb = 0, LdsPart Lp = LdsPart{nullptr, 0, 0}) {
   const uint32_t s = (uint32_t)hash64_2((uint64_t)a) & hmask;
   uint32_t old, w;
   const uint32_t hm = (1u << hb) - 1u;
   const bool in_hbm = (s & hm) == hm;                                   // always true when hb == 0
-  uint32_t* Hp = reinterpret_cast<uint32_t*>(T + 1024);                 // LDS part of a split table
   if constexpr (HASH_LDS) {
     old = active ? H[s] : 0u;
     PANN_WSYNC();
@@ -146,7 +175,7 @@ __device__ __forceinline__ bool filter_update(uint32_t* H, uint32_t hmask, bool 
   } else {
     __builtin_amdgcn_s_waitcnt(0);                       // the previous call's table stores have been acknowledged
     old = 0u;
-    if (active) old = in_hbm ? __hip_atomic_load(H + (s >> hb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : Hp[split_lds_index(s, hb)];
+    if (active) old = in_hbm ? __hip_atomic_load(H + (s >> hb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : lds_part_load(Lp, split_lds_index(s, hb));
     const uint32_t t = s & 1023u;
     if (active) T[t] = (uint8_t)lane;
     PANN_WSYNC();
@@ -175,7 +204,7 @@ __device__ __forceinline__ bool filter_update(uint32_t* H, uint32_t hmask, bool 
   } else {
     if (active && last) {
       if (in_hbm) __hip_atomic_store(H + (s >> hb), a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else Hp[split_lds_index(s, hb)] = a;
+      else lds_part_store(Lp, split_lds_index(s, hb), a);
     }
     PANN_WSYNC();                                     // T (and the LDS part) may be touched by the next call
   }
@@ -684,13 +713,14 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
   uint64_t* C = S + 64 * RB;                                // [ccap] candidates (unsorted)
   uint8_t* Sv = reinterpret_cast<uint8_t*>(C + P.ccap);     // [128] flags of the scatter scratch
   uint4* qlds = reinterpret_cast<uint4*>(Sv + 64 * RB);     // [nch*LPC] query (generic variant)
-  uint32_t* Hl = reinterpret_cast<uint32_t*>(qlds + (NCH1 ? 0 : P.nch * LPC));  // [1<<bits] if HASH_LDS, else 1 KB replay scratch
-  uint8_t* T = reinterpret_cast<uint8_t*>(Hl);
+  uint32_t* Hl = reinterpret_cast<uint32_t*>(qlds + (NCH1 ? 0 : P.nch * LPC));  // [1<<bits] if HASH_LDS, else the LDS part of a split table
+  uint8_t* T = reinterpret_cast<uint8_t*>(S);               // 1 KB replay scratch of the HBM-table filter: S is idle outside the merge
   uint32_t* Pl = reinterpret_cast<uint32_t*>(S);
 
   const uint32_t hsize = 1u << P.bits, hmask = hsize - 1u;
   const uint32_t beam = P.beam;
   const uint32_t BIG_ORD = f2ord(2147483648.0f);
+  const LdsPart Lp{reinterpret_cast<uint8_t*>(Hl), HASH_LDS ? 0u : (P.hsplit ? hsize - (hsize >> P.hsplit) : 0u), P.p24};
   // filter in LDS: one query per block.  Filter in HBM (16 KB of LDS would cap a CU at 8 queries): persistent
   // blocks, one table per block, queries pulled from a counter.
   uint32_t qi = blockIdx.x;
@@ -703,7 +733,7 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
   uint32_t* H = HASH_LDS ? Hl : P.hash_global + ((size_t)blockIdx.x << P.bits);
   const uint32_t hb = HASH_LDS ? 0u : P.hsplit;
   for (uint32_t i = lane; i < (hsize >> hb); i += PANN_WAVE) hstore<HASH_LDS>(H, i, SENTINEL);
-  if (hb) for (uint32_t i = lane; i < hsize - (hsize >> hb); i += PANN_WAVE) reinterpret_cast<uint32_t*>(T + 1024)[i] = SENTINEL;
+  if (hb) lds_part_clear(Lp, lane);
   const int64_t self = P.query_ids ? (int64_t)P.query_ids[qi] : -1;
   const uint8_t* qrow = P.query_ids ? P.points + (uint64_t)self * P.pstride : P.queries + (uint64_t)qi * P.qstride;
   QReg<DT> qreg{};
@@ -725,7 +755,7 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
   {   // start points (:66-70); nstarts <= 64 in this kernel
     const bool act = lane < (int)P.nstarts;
     const uint32_t a = act ? P.starts[(size_t)qi * P.starts_stride + lane] : 0u;
-    (void)filter_update<HASH_LDS>(H, hmask, act, a, lane, T, hb);
+    (void)filter_update<HASH_LDS>(H, hmask, act, a, lane, T, hb, Lp);
     if (act) Pl[lane] = a;
     PANN_WSYNC();
     c = gather_distances<DT, METRIC, LPC, NCH1, 4, false>(P, qreg, qlds, Pl, P.nstarts, 0xFFFFFFFFu, C, c, lane);
@@ -783,7 +813,7 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
         PANN_STAMP(1);
         if (am == 0ull) break;
         degsum += __popcll(am);
-        const bool seen = filter_update<HASH_LDS>(H, hmask, act, a, lane, T, hb);
+        const bool seen = filter_update<HASH_LDS>(H, hmask, act, a, lane, T, hb, Lp);
         const bool keep = act && !seen && ((int64_t)a != self);
         const uint64_t km = __ballot(keep);
         const uint32_t m = __popcll(km);
@@ -955,6 +985,7 @@ struct Plan {
   uint32_t bits, bcap, ccap, deg_eff, dcap, lds_bytes; bool hash_lds; uint32_t slots; bool b64; bool b128;
   bool b128_hbm;   // beam 65..128 with the filter in HBM (persistent blocks)
   uint32_t hsplit; // ... of which the part with an LDS share (filter_update split mode)
+  uint32_t p24;    // ... stored as planar 24-bit entries
 };
 
 static Plan make_plan(const DeviceIndex& ix, const SearchArgs& a) {
@@ -995,7 +1026,10 @@ static Plan make_plan(const DeviceIndex& ix, const SearchArgs& a) {
       p.hsplit = sp ? (uint32_t)atoi(sp) : 1u;     // measured: half in LDS 2.99 M q/s, none 2.46, three quarters 2.67, whole table in LDS 2.28
       if (p.hsplit > 2) p.hsplit = 0;
       p.hash_lds = false; p.slots = 256 * 32;
-      hbytes = 1024 + (p.hsplit ? (((size_t)1 << p.bits) - ((size_t)1 << (p.bits - p.hsplit))) * 4 : 0);
+      static const bool no24 = getenv("PANN_B128_NO24") != nullptr;              // diagnostic A/B switch
+      p.p24 = (p.hsplit && ix.n < 0xFFFFFFull && !no24) ? 1u : 0u;
+      // the 1 KB replay scratch of filter_update aliases the merge scratch S; the LDS share of the table follows the query
+      hbytes = p.hsplit ? (((size_t)1 << p.bits) - ((size_t)1 << (p.bits - p.hsplit))) * (p.p24 ? 3 : 4) : 0;
     }
     p.lds_bytes = (uint32_t)(128 * 8 + (size_t)p.ccap * 8 + 128 + (nch1 ? 0 : (size_t)ix.nch * ix.lpc * 16) + hbytes);
   }
@@ -1091,6 +1125,7 @@ int launch_beam_search(const DeviceIndex& ix, const SearchArgs& a, void* ws, siz
     P.prio_start = tenths >= 10 ? 0xFFFFFFFFu : (uint32_t)((uint64_t)a.nq * tenths / 10);
   }
   P.hsplit = p.b128_hbm ? p.hsplit : 0u;
+  P.p24 = p.b128_hbm ? p.p24 : 0u;
   P.hash_global = p.hash_lds ? nullptr : (uint32_t*)(w + 256 + (size_t)a.nq * p.dcap * 8);
   P.out = a.out;
   P.stamps = nullptr;

@@ -466,17 +466,22 @@ int hcnng_build_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, uint32
     const uint32_t nleaves = (uint32_t)leaf_off.size() - 1;
 
     // ---- all-pairs 10-NN of every leaf (device ids, no host copy) ----
-    std::vector<uint32_t> tseg, ta0;
-    for (uint32_t l = 0; l < nleaves; l++)
-      for (uint64_t a = leaf_off[l]; a < leaf_off[l + 1]; a += 64) { tseg.push_back(l); ta0.push_back((uint32_t)a); }
     HBuf d_loff, d_tseg, d_ta0, d_seg_b, d_seg_e;
-    if (d_loff.alloc((nleaves + 1) * 8) || d_tseg.alloc(tseg.size() * 4) || d_ta0.alloc(ta0.size() * 4) || d_seg_b.alloc(nleaves * 4) ||
-        d_seg_e.alloc(nleaves * 4)) { set_error("pann_hcnng_build: hipMalloc failed"); return PANN_ERR_HIP; }
+    if (d_loff.alloc((nleaves + 1) * 8) || d_seg_b.alloc(nleaves * 4) || d_seg_e.alloc(nleaves * 4)) { set_error("pann_hcnng_build: hipMalloc failed"); return PANN_ERR_HIP; }
     PANN_HIP(hipMemcpyAsync(d_loff.p, leaf_off.data(), (nleaves + 1) * 8, hipMemcpyHostToDevice, st));
-    PANN_HIP(hipMemcpyAsync(d_tseg.p, tseg.data(), tseg.size() * 4, hipMemcpyHostToDevice, st));
-    PANN_HIP(hipMemcpyAsync(d_ta0.p, ta0.data(), ta0.size() * 4, hipMemcpyHostToDevice, st));
-    if (int rc = dense_topk_dev(ix, ws, st, nullptr, 0, ids, ids, d_loff.as<uint64_t>(), d_loff.as<uint64_t>(), d_tseg.as<uint32_t>(),
-                                d_ta0.as<uint32_t>(), (uint32_t)tseg.size(), n, n, 1, m, 1, b_nnids.as<uint32_t>(), b_nnd.as<float>())) return rc;
+    if (leaf_knn_rows_eligible(ix, m)) {     // one-byte element types: lane-owns-row kernel (leaf_knn.hip)
+      if (int rc = leaf_knn_rows_dev(ix, ws, st, ids, d_loff.as<uint64_t>(), leaf_off.data(), nleaves, m, 1, b_nnids.as<uint32_t>(), b_nnd.as<float>())) return rc;
+    } else {
+      std::vector<uint32_t> tseg, ta0;
+      for (uint32_t l = 0; l < nleaves; l++)
+        for (uint64_t a = leaf_off[l]; a < leaf_off[l + 1]; a += 64) { tseg.push_back(l); ta0.push_back((uint32_t)a); }
+      if (d_tseg.alloc(tseg.size() * 4) || d_ta0.alloc(ta0.size() * 4)) { set_error("pann_hcnng_build: hipMalloc failed"); return PANN_ERR_HIP; }
+      PANN_HIP(hipMemcpyAsync(d_tseg.p, tseg.data(), tseg.size() * 4, hipMemcpyHostToDevice, st));
+      PANN_HIP(hipMemcpyAsync(d_ta0.p, ta0.data(), ta0.size() * 4, hipMemcpyHostToDevice, st));
+      if (int rc = dense_topk_dev(ix, ws, st, nullptr, 0, ids, ids, d_loff.as<uint64_t>(), d_loff.as<uint64_t>(), d_tseg.as<uint32_t>(),
+                                  d_ta0.as<uint32_t>(), (uint32_t)tseg.size(), n, n, 1, m, 1, b_nnids.as<uint32_t>(), b_nnd.as<float>())) return rc;
+      PANN_HIP(hipStreamSynchronize(st));        // the host tile vectors go out of scope
+    }
     PANN_HIP(hipStreamSynchronize(st));
     const auto t2 = now();
 

@@ -100,6 +100,11 @@ int rerank_dev(const DeviceIndex& ix, hipStream_t st, const uint8_t* d_q, uint64
                const uint32_t* d_cand, uint32_t c, const uint32_t* d_cnt, uint32_t k, int resort, uint32_t* d_out_ids,
                float* d_out_dists);
 
+// leaf_knn.hip: lane-owns-row all-pairs top-m for one-byte element types (HCNNG leaves)
+bool leaf_knn_rows_eligible(const DeviceIndex& ix, uint32_t m);
+int leaf_knn_rows_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, const uint32_t* d_ids, const uint64_t* d_off,
+                      const uint64_t* h_off, uint64_t nseg, uint32_t m, int exclude_same, uint32_t* d_out_ids, float* d_out_dists);
+
 // range_search.hip
 int range_search_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, const uint8_t* d_q, uint64_t q_stride,
                      const uint32_t* d_qids, uint64_t nq, const uint32_t* d_starts, uint32_t nstarts,

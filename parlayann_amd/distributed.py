@@ -72,8 +72,10 @@ def all_gather_tensor(t):
         return t.unsqueeze(0)
     staged = t.is_cuda and dist.get_backend() != "nccl"
     src = (t.cpu() if staged else t).contiguous()
-    out = torch.empty((world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
-    dist.all_gather_into_tensor(out, src)
+    flat = src.reshape(-1)                        # the concatenated form: accepted by gloo and nccl alike
+    out = torch.empty(world * flat.numel(), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(out, flat)
+    out = out.reshape((world,) + tuple(src.shape))
     return out.to(t.device) if staged else out
 
 

@@ -117,7 +117,8 @@ int main(int argc, char** argv) {
   }
   // ---- range_search(p, G, Points, starting_points, radius, radius_2, QP, use_existing)   :245-252 ----
   {
-    parlay::sequence<indexType> s0 = {0, 17};
+    // starts: two vertices inside the radius (only those seed the BFS, :271-277) and one outside
+    parlay::sequence<indexType> s0 = {(indexType)std::atol(argc > 7 ? argv[7] : "0"), (indexType)std::atol(argc > 8 ? argv[8] : "17"), 0};
     QueryParams q2 = QP;
     const float r2 = (float)std::atof(argc > 6 ? argv[6] : "50000");
     auto r = range_search(Query_Points[2], G, Points, s0, 0.0f, r2, q2, false);

@@ -32,15 +32,17 @@ def run(tmp_path_factory, oracle):
     G, _ = oracle.vamana_build(X, 32, 48, 1.2, num_passes=1, seed=5)
     gt, gd = oracle.bruteforce_knn(X, Q, 100)
     io.write_bin(d / "base.bin", X); io.write_bin(d / "query.bin", Q); io.write_graph(d / "g.graph", G); io.write_ibin(d / "gt.ibin", gt, gd)
-    r2 = float(np.median(oracle.bruteforce_knn(X, Q[2:3], 40)[1][:, -1]))
+    nn_i, nn_d = oracle.bruteforce_knn(X, Q[2:3], 40)
+    r2 = float(nn_d[0, -1])                                        # radius: the query's 40 nearest base points
+    rs = [int(nn_i[0, 3]), int(nn_i[0, 20])]                       # two starts inside it
     out = d / "out"; out.mkdir()
-    p = subprocess.run([build_checker(), str(d / "base.bin"), str(d / "query.bin"), str(d / "g.graph"), str(d / "gt.ibin"), str(out), repr(r2)],
-                       capture_output=True, text=True)
+    p = subprocess.run([build_checker(), str(d / "base.bin"), str(d / "query.bin"), str(d / "g.graph"), str(d / "gt.ibin"), str(out), repr(r2),
+                        str(rs[0]), str(rs[1])], capture_output=True, text=True)
     assert p.returncode == 0 and "host_api_check done" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
 
     def load(name, dt):
         return np.fromfile(out / (name + ".bin"), dtype=dt)
-    return dict(X=X, Q=Q, G=G, gt=gt, gd=gd, load=load, out=out, stdout=p.stdout, r2=r2)
+    return dict(X=X, Q=Q, G=G, gt=gt, gd=gd, load=load, out=out, stdout=p.stdout, r2=r2, rs=rs)
 
 
 def _sorted_visited(o, i, cap):
@@ -108,7 +110,7 @@ def test_batched_searches(run, oracle):
 
 def test_range_search_and_check_recall(run, oracle):
     ld, X, Q, G = run["load"], run["X"], run["Q"], run["G"]
-    o = oracle.range_search(X, G, [0, 17], run["r2"], 4096, queries=Q[2:3])
+    o = oracle.range_search(X, G, run["rs"] + [0], run["r2"], 4096, queries=Q[2:3])
     c = int(o["counts"][0])
     assert c > 5
     np.testing.assert_array_equal(ld("range_ids", np.uint32), o["ids"][0, :c])

@@ -59,11 +59,21 @@ def two_ranks():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    import queue
+    import time
+    res, t0 = [], time.time()
+    while len(res) < world:                       # a rank that died must fail the test at once, not after a long silent wait
+        try:
+            res.append(q.get(timeout=5))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            assert not dead, f"a rank exited with {dead} (its traceback is on stderr)"
+            assert time.time() - t0 < 400, "ranks did not finish in 400 s"
+            print(f"[two_ranks] waiting, {time.time() - t0:.0f}s", flush=True)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    return res
+    return sorted(res, key=lambda t: t[0])
 
 
 def test_sharded_index_equals_per_shard_oracle_merged(two_ranks, oracle):
