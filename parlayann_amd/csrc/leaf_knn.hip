@@ -8,7 +8,7 @@
 // 4 dwords), so the loop is bound by the dot-product issue rate, not by LDS (the round-1 kernel read 18 chunks per 128 v_dot4
 // and re-staged per 64 A rows behind two barriers per tile: 5-8 % of the v_dot4 peak).
 //
-// Top-m: a distance that beats its row's current m-th best is queued (8-entry per-row queue in LDS, private to the lane); the
+// Top-m: a distance that beats its row's current m-th best is queued (4-entry per-row queue in LDS, private to the lane); the
 // wave empties all queues together -- one compare-exchange chain pass per queue slot -- when some queue is full, so the
 // divergent insert is paid once per ~100 accepted candidates of the wave instead of once per candidate.
 // Integer arithmetic: sums are exact in int32 (euclidian_point.h:54-62,74-81; mips_point.h:43-57), one cast to float at the
@@ -20,8 +20,8 @@
 namespace pann {
 
 constexpr int LK_ROWS = 256;    // A rows per workgroup (2 waves x 2 rows per lane)
-constexpr int LK_TB = 64;       // B rows staged per step
-constexpr int LK_PD = 8;        // pending-queue depth per row
+constexpr int LK_TB = 128;      // B rows staged per step
+constexpr int LK_PD = 4;        // pending-queue depth per row
 
 struct LeafArgs {
   const uint8_t* points; uint32_t pstride;
@@ -44,17 +44,15 @@ __device__ __forceinline__ void lk_chain_insert(uint64_t (&L)[MC], uint64_t x) {
 }
 
 template <int DT>
+__device__ __forceinline__ int lk_dot4(uint32_t a, uint32_t b, int acc) {
+  if constexpr (DT == PANN_U8) return (int)__builtin_amdgcn_udot4(a, b, (uint32_t)acc, false);
+  else return __builtin_amdgcn_sdot4((int)a, (int)b, acc, false);
+}
+template <int DT>
 __device__ __forceinline__ int lk_dot16(const uint4& a, const uint4& b, int acc) {
-  if constexpr (DT == PANN_U8) {
-    uint32_t t = (uint32_t)acc;
-    t = __builtin_amdgcn_udot4(a.x, b.x, t, false); t = __builtin_amdgcn_udot4(a.y, b.y, t, false);
-    t = __builtin_amdgcn_udot4(a.z, b.z, t, false); t = __builtin_amdgcn_udot4(a.w, b.w, t, false);
-    return (int)t;
-  } else {
-    acc = __builtin_amdgcn_sdot4((int)a.x, (int)b.x, acc, false); acc = __builtin_amdgcn_sdot4((int)a.y, (int)b.y, acc, false);
-    acc = __builtin_amdgcn_sdot4((int)a.z, (int)b.z, acc, false); acc = __builtin_amdgcn_sdot4((int)a.w, (int)b.w, acc, false);
-    return acc;
-  }
+  acc = lk_dot4<DT>(a.x, b.x, acc); acc = lk_dot4<DT>(a.y, b.y, acc);
+  acc = lk_dot4<DT>(a.z, b.z, acc); acc = lk_dot4<DT>(a.w, b.w, acc);
+  return acc;
 }
 
 template <int DT, int METRIC, int NCH, int MC>
@@ -72,6 +70,7 @@ __global__ void __launch_bounds__(128) leaf_knn_kernel(LeafArgs A) {
   uint4 a[2][NCH];
   uint32_t aid[2]; bool valid[2]; int aa[2];
   uint64_t L[2][MC], tau[2]; uint32_t npend[2];
+  float taud[2];                       // key_dist(tau): the m-th best distance so far (+inf until the list is full)
 #pragma unroll
   for (int r = 0; r < 2; r++) {
     const uint64_t ar = a0 + (uint64_t)wave * 128 + r * 64 + lane;
@@ -86,7 +85,7 @@ __global__ void __launch_bounds__(128) leaf_knn_kernel(LeafArgs A) {
     }
 #pragma unroll
     for (int i = 0; i < MC; i++) L[r][i] = (i < MC - (int)A.m) ? 0ull : KEY_INF;     // leading key-0 entries are never displaced
-    tau[r] = KEY_INF; npend[r] = 0;
+    tau[r] = KEY_INF; npend[r] = 0; taud[r] = __builtin_inff();
   }
   uint64_t* myq = Pq + (size_t)tid * 2 * LK_PD;
 
@@ -100,6 +99,7 @@ __global__ void __launch_bounds__(128) leaf_knn_kernel(LeafArgs A) {
           if (x < tau[r]) { lk_chain_insert<MC>(L[r], x); tau[r] = L[r][MC - 1]; }
         }
       }
+      taud[r] = (tau[r] == KEY_INF) ? __builtin_inff() : key_dist(tau[r]);
       npend[r] = 0;
     }
   };
@@ -124,26 +124,39 @@ __global__ void __launch_bounds__(128) leaf_knn_kernel(LeafArgs A) {
       }
       __syncthreads();
     }
+    // B row j's chunks sit in b[]; each register is refilled with the NEXT row's chunk right after its last use, so the
+    // broadcast reads of row j + 1 are in flight during the dot products of row j (one row of software pipelining in the
+    // registers the row occupies anyway; the read past the last row of the tile is clamped and unused)
+    uint4 b[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) b[c] = Bt[c];
     for (uint32_t j = 0; j < nb; j++) {
-      int acc[2] = {0, 0};
+      // two accumulators per A row (even / odd dwords): four independent v_dot4 chains per wave
+      int acc0[2] = {0, 0}, acc1[2] = {0, 0};
+      uint32_t nxt = min(j + 1, (uint32_t)LK_TB - 1) * NCH;
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
-        const uint4 b = Bt[j * NCH + c];               // every lane reads the same address: one broadcast
-        acc[0] = lk_dot16<DT>(a[0][c], b, acc[0]);
-        acc[1] = lk_dot16<DT>(a[1][c], b, acc[1]);
+        acc0[0] = lk_dot4<DT>(a[0][c].x, b[c].x, acc0[0]); acc1[0] = lk_dot4<DT>(a[1][c].x, b[c].x, acc1[0]);
+        acc0[1] = lk_dot4<DT>(a[0][c].y, b[c].y, acc0[1]); acc1[1] = lk_dot4<DT>(a[1][c].y, b[c].y, acc1[1]);
+        acc0[0] = lk_dot4<DT>(a[0][c].z, b[c].z, acc0[0]); acc1[0] = lk_dot4<DT>(a[1][c].z, b[c].z, acc1[0]);
+        acc0[1] = lk_dot4<DT>(a[0][c].w, b[c].w, acc0[1]); acc1[1] = lk_dot4<DT>(a[1][c].w, b[c].w, acc1[1]);
+        // the refill's address is made to depend on the sums just updated (an empty asm, no instruction): the read cannot
+        // be hoisted above the uses of b[c], so it lands in the registers they free instead of in a second buffer
+        asm volatile("" : "+v"(nxt) : "v"(acc0[0]), "v"(acc0[1]), "v"(acc1[0]), "v"(acc1[1]));
+        b[c] = Bt[nxt + c];                            // every lane reads the same address: one broadcast
       }
+      const int acc[2] = {acc0[0] + acc0[1], acc1[0] + acc1[1]};
       const uint32_t bid = Bid[j];
 #pragma unroll
       for (int r = 0; r < 2; r++) {
+        // cheap test first: one conversion and one float compare against the row's current m-th best distance (a tie
+        // still passes: the id decides below); the key is only built for the few that get through
         float dist;
         if constexpr (METRIC == PANN_L2) dist = (float)(aa[r] + Bnn[j] - 2 * acc[r]);
         else dist = -(float)acc[r];
-        const uint32_t ord = f2ord(dist);
-        bool pass = valid[r] && ord <= (uint32_t)(tau[r] >> 32);
-        if (A.exclude_same_id) pass = pass && (bid != aid[r]);
-        if (pass) {
-          const uint64_t key = ((uint64_t)ord << 32) | bid;
-          if (key < tau[r]) { myq[r * LK_PD + npend[r]] = key; npend[r]++; }
+        if (valid[r] && dist <= taud[r]) {
+          const uint64_t key = make_key(dist, bid);
+          if (key < tau[r] && !(A.exclude_same_id && bid == aid[r])) { myq[r * LK_PD + npend[r]] = key; npend[r]++; }
         }
       }
       if (__any(npend[0] == LK_PD || npend[1] == LK_PD)) flush();
