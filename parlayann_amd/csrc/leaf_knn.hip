@@ -8,7 +8,7 @@
 // 4 dwords), so the loop is bound by the dot-product issue rate, not by LDS (the round-1 kernel read 18 chunks per 128 v_dot4
 // and re-staged per 64 A rows behind two barriers per tile: 5-8 % of the v_dot4 peak).
 //
-// Top-m: a distance that beats its row's current m-th best is queued (4-entry per-row queue in LDS, private to the lane); the
+// Top-m: a distance that beats its row's current m-th best is queued (8-entry per-row queue in LDS, private to the lane); the
 // wave empties all queues together -- one compare-exchange chain pass per queue slot -- when some queue is full, so the
 // divergent insert is paid once per ~100 accepted candidates of the wave instead of once per candidate.
 // Integer arithmetic: sums are exact in int32 (euclidian_point.h:54-62,74-81; mips_point.h:43-57), one cast to float at the
@@ -20,8 +20,8 @@
 namespace pann {
 
 constexpr int LK_ROWS = 256;    // A rows per workgroup (2 waves x 2 rows per lane)
-constexpr int LK_TB = 128;      // B rows staged per step
-constexpr int LK_PD = 4;        // pending-queue depth per row
+constexpr int LK_TB = 64;       // B rows staged per step
+constexpr int LK_PD = 8;        // pending-queue depth per row
 
 struct LeafArgs {
   const uint8_t* points; uint32_t pstride;
@@ -42,6 +42,10 @@ __device__ __forceinline__ void lk_chain_insert(uint64_t (&L)[MC], uint64_t x) {
     L[i] = lo; x = hi;
   }
 }
+
+typedef uint32_t lk_u32x4 __attribute__((ext_vector_type(4)));
+// LDS byte address of a __shared__ object (the low 32 bits of its flat address are its LDS offset)
+__device__ __forceinline__ uint32_t lk_lds_addr(const void* p) { return (uint32_t)(uintptr_t)p; }
 
 template <int DT>
 __device__ __forceinline__ int lk_dot4(uint32_t a, uint32_t b, int acc) {
@@ -126,33 +130,48 @@ __global__ void __launch_bounds__(128) leaf_knn_kernel(LeafArgs A) {
     }
     // B row j's chunks sit in b[]; each register is refilled with the NEXT row's chunk right after its last use, so the
     // broadcast reads of row j + 1 are in flight during the dot products of row j (one row of software pipelining in the
-    // registers the row occupies anyway; the read past the last row of the tile is clamped and unused)
-    uint4 b[NCH];
+    // registers the row occupies anyway).  The reads and their waits are issued by hand: LDS returns in order, and the
+    // compiler's own s_waitcnt placement for such loop-carried reads drains all but the two youngest before every chunk
+    // (measured: 42 % of the wave cycles waiting).  Here every use waits with lgkmcnt(LK_WAIT = LK_INFLIGHT - 1): the wanted read is
+    // the oldest of the LK_INFLIGHT that are outstanding (NCH chunks + the id word [+ the norm word]), a full row old.
+    constexpr int LK_INFLIGHT = NCH + (METRIC == PANN_L2 ? 2 : 1);
+    constexpr int LK_WAIT = LK_INFLIGHT - 1 <= 15 ? LK_INFLIGHT - 1 : 15;      // lgkmcnt is a 4-bit counter; a smaller count only waits for more
+    lk_u32x4 b[NCH];
+    uint32_t bid_next, bnn_next = 0;
+    {
+      const uint32_t base = lk_lds_addr(Bt);
 #pragma unroll
-    for (int c = 0; c < NCH; c++) b[c] = Bt[c];
+      for (int c = 0; c < NCH; c++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[c]) : "v"(base), "n"(c * 16));
+      asm volatile("ds_read_b32 %0, %1" : "=v"(bid_next) : "v"(lk_lds_addr(Bid)));
+      if constexpr (METRIC == PANN_L2) asm volatile("ds_read_b32 %0, %1" : "=v"(bnn_next) : "v"(lk_lds_addr(Bnn)));
+    }
     for (uint32_t j = 0; j < nb; j++) {
       // two accumulators per A row (even / odd dwords): four independent v_dot4 chains per wave
       int acc0[2] = {0, 0}, acc1[2] = {0, 0};
-      uint32_t nxt = min(j + 1, (uint32_t)LK_TB - 1) * NCH;
+      const uint32_t jn = min(j + 1, (uint32_t)LK_TB - 1);
+      const uint32_t nxt = lk_lds_addr(Bt) + jn * (NCH * 16);
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(b[c]) : "n"(LK_WAIT));
         acc0[0] = lk_dot4<DT>(a[0][c].x, b[c].x, acc0[0]); acc1[0] = lk_dot4<DT>(a[1][c].x, b[c].x, acc1[0]);
         acc0[1] = lk_dot4<DT>(a[0][c].y, b[c].y, acc0[1]); acc1[1] = lk_dot4<DT>(a[1][c].y, b[c].y, acc1[1]);
         acc0[0] = lk_dot4<DT>(a[0][c].z, b[c].z, acc0[0]); acc1[0] = lk_dot4<DT>(a[1][c].z, b[c].z, acc1[0]);
         acc0[1] = lk_dot4<DT>(a[0][c].w, b[c].w, acc0[1]); acc1[1] = lk_dot4<DT>(a[1][c].w, b[c].w, acc1[1]);
-        // the refill's address is made to depend on the sums just updated (an empty asm, no instruction): the read cannot
-        // be hoisted above the uses of b[c], so it lands in the registers they free instead of in a second buffer
-        asm volatile("" : "+v"(nxt) : "v"(acc0[0]), "v"(acc0[1]), "v"(acc1[0]), "v"(acc1[1]));
-        b[c] = Bt[nxt + c];                            // every lane reads the same address: one broadcast
+        // the refill is ordered behind the sums just updated (they are inputs of the asm), so it reuses the registers of b[c]
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[c]) : "v"(nxt), "n"(c * 16), "v"(acc0[0]), "v"(acc0[1]), "v"(acc1[0]), "v"(acc1[1]));
       }
+      uint32_t bid = bid_next; int bnn = (int)bnn_next;
+      if constexpr (METRIC == PANN_L2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bid), "+v"(bnn) : "n"(LK_WAIT));
+      else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bid) : "n"(LK_WAIT));
+      asm volatile("ds_read_b32 %0, %1" : "=v"(bid_next) : "v"(lk_lds_addr(Bid) + jn * 4), "v"(bid));
+      if constexpr (METRIC == PANN_L2) asm volatile("ds_read_b32 %0, %1" : "=v"(bnn_next) : "v"(lk_lds_addr(Bnn) + jn * 4), "v"(bnn));
       const int acc[2] = {acc0[0] + acc0[1], acc1[0] + acc1[1]};
-      const uint32_t bid = Bid[j];
 #pragma unroll
       for (int r = 0; r < 2; r++) {
         // cheap test first: one conversion and one float compare against the row's current m-th best distance (a tie
         // still passes: the id decides below); the key is only built for the few that get through
         float dist;
-        if constexpr (METRIC == PANN_L2) dist = (float)(aa[r] + Bnn[j] - 2 * acc[r]);
+        if constexpr (METRIC == PANN_L2) dist = (float)(aa[r] + bnn - 2 * acc[r]);
         else dist = -(float)acc[r];
         if (valid[r] && dist <= taud[r]) {
           const uint64_t key = make_key(dist, bid);
@@ -161,6 +180,7 @@ __global__ void __launch_bounds__(128) leaf_knn_kernel(LeafArgs A) {
       }
       if (__any(npend[0] == LK_PD || npend[1] == LK_PD)) flush();
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the clamped reads past the tile's last row have landed
   }
   flush();
 #pragma unroll
