@@ -50,8 +50,9 @@ extern "C" {
 #define PANN_ERR_OVERFLOW 5 /* a per-query device buffer (visited list) was too small */
 
 /* element type of the stored vectors (reference: Euclidian_Point<T>/Mips_Point<T>, T in
- * {uint8_t,int8_t,float}; PANN_F16 is this build's extension) */
-typedef enum { PANN_U8 = 0, PANN_I8 = 1, PANN_F32 = 2, PANN_F16 = 3 } pann_dtype;
+ * {uint8_t,int8_t,float}; PANN_F16 (IEEE binary16) and PANN_BF16 (bfloat16) are this build's two-byte
+ * extensions: values are widened exactly to f32, arithmetic is f32) */
+typedef enum { PANN_U8 = 0, PANN_I8 = 1, PANN_F32 = 2, PANN_F16 = 3, PANN_BF16 = 4 } pann_dtype;
 
 /* distance functor: euclidian_point.h:54-90 / mips_point.h:43-65 */
 typedef enum { PANN_L2 = 0, PANN_MIPS = 1 } pann_metric;

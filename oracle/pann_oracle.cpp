@@ -30,7 +30,7 @@
 
 namespace {
 
-enum { DT_U8 = 0, DT_I8 = 1, DT_F32 = 2, DT_F16 = 3 };
+enum { DT_U8 = 0, DT_I8 = 1, DT_F32 = 2, DT_F16 = 3, DT_BF16 = 4 };
 enum { M_L2 = 0, M_MIPS = 1 };
 
 // parlaylib include/parlay/utilities.h hash64_2 (used at beamSearch.h:55)
@@ -61,6 +61,14 @@ inline float half_to_float(uint16_t h) {
   } else {
     bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
   }
+  float f;
+  std::memcpy(&f, &bits, 4);
+  return f;
+}
+
+// bfloat16 -> binary32: the 16 bits are the float's upper half, exact
+inline float bf16_to_float(uint16_t h) {
+  const uint32_t bits = (uint32_t)h << 16;
   float f;
   std::memcpy(&f, &bits, 4);
   return f;
@@ -100,14 +108,15 @@ float distance(int dtype, int metric, const void* pa, const void* pb, unsigned d
     for (unsigned i = 0; i < d; i++) r += q[i] * p[i];
     return -r;
   }
-  // DT_F16: convert, then the f32 rule
+  // DT_F16 / DT_BF16 (extensions of this build: two-byte storage, arithmetic in f32): convert exactly, then the f32 rule
   const uint16_t* p = (const uint16_t*)pa; const uint16_t* q = (const uint16_t*)pb;
+  auto cv = [dtype](uint16_t h) { return dtype == DT_BF16 ? bf16_to_float(h) : half_to_float(h); };
   float r = 0.0f;
   if (metric == M_L2) {
-    for (unsigned i = 0; i < d; i++) { float t = half_to_float(q[i]) - half_to_float(p[i]); r += t * t; }
+    for (unsigned i = 0; i < d; i++) { float t = cv(q[i]) - cv(p[i]); r += t * t; }
     return r;
   }
-  for (unsigned i = 0; i < d; i++) r += half_to_float(q[i]) * half_to_float(p[i]);
+  for (unsigned i = 0; i < d; i++) r += cv(q[i]) * cv(p[i]);
   return -r;
 }
 
@@ -191,7 +200,7 @@ void beam_search(const Dataset& D, const void* q, int64_t self_id, const uint32_
       uint32_t a = row[1 + i];
       if (seen(a) || (int64_t)a == self_id) continue;  // :133 (filter is updated before same_as)
       // Q_Points[a].prefetch() (:134; euclidian_point.h:129-133): one prefetch per 64-byte line of the row
-      for (uint64_t off = 0; off < (uint64_t)D.d * (D.dtype == DT_F32 ? 4 : D.dtype == DT_F16 ? 2 : 1); off += 64)
+      for (uint64_t off = 0; off < (uint64_t)D.d * (D.dtype == DT_F32 ? 4 : (D.dtype == DT_F16 || D.dtype == DT_BF16) ? 2 : 1); off += 64)
         __builtin_prefetch((const char*)D.row(a) + off);
       keep.push_back(a);
     }
@@ -742,7 +751,7 @@ void hc_cluster(const Dataset& D, std::vector<uint32_t>& act, uint64_t rnd, size
   const size_t si = su < fi ? su : su + 1;
   const uint32_t f = act[fi], s = act[si];
   std::vector<uint32_t> a, b;
-  bool same = std::memcmp(D.row(f), D.row(s), (size_t)D.d * (D.dtype == DT_F32 ? 4 : D.dtype == DT_F16 ? 2 : 1)) == 0;   // Points[f] == Points[s] :107
+  bool same = std::memcmp(D.row(f), D.row(s), (size_t)D.d * (D.dtype == DT_F32 ? 4 : (D.dtype == DT_F16 || D.dtype == DT_BF16) ? 2 : 1)) == 0;   // Points[f] == Points[s] :107
   if (!same) {
     for (uint32_t id : act) {                                                  // :71-83
       float df = D.dist_ids(id, f), ds = D.dist_ids(id, s);

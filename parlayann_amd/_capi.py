@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpann.so")
 if os.environ.get("PANN_LIBRARY"):      # A/B runs of diagnostic builds (tools/): same ABI, another file
     LIB_PATH = os.environ["PANN_LIBRARY"]
 
-PANN_U8, PANN_I8, PANN_F32, PANN_F16 = 0, 1, 2, 3
+PANN_U8, PANN_I8, PANN_F32, PANN_F16, PANN_BF16 = 0, 1, 2, 3, 4
 PANN_L2, PANN_MIPS = 0, 1
 PANN_OK = 0
 PANN_ERR_OVERFLOW = 5

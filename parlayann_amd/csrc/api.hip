@@ -76,7 +76,7 @@ struct pann_index {
 namespace {
 
 static uint32_t esize_of(int dtype) {
-  switch (dtype) { case PANN_U8: case PANN_I8: return 1; case PANN_F16: return 2; case PANN_F32: return 4; }
+  switch (dtype) { case PANN_U8: case PANN_I8: return 1; case PANN_F16: case PANN_BF16: return 2; case PANN_F32: return 4; }
   return 0;
 }
 
@@ -253,7 +253,7 @@ int pann_index_device(const pann_index* idx) { return idx ? idx->device : -1; }
 int pann_index_set_exact_float_order(pann_index* idx, int on) {
   if (int rc = check_idx(idx, "pann_index_set_exact_float_order")) return rc;
   DeviceIndex& ix = idx->ix;
-  const bool is_float = ix.dtype == PANN_F32 || ix.dtype == PANN_F16;
+  const bool is_float = ix.dtype == PANN_F32 || ix.dtype == PANN_F16 || ix.dtype == PANN_BF16;
   if (on && is_float) { ix.exact = 1; ix.lpc = 4; ix.nch = ix.pstride / 64; }   // whole query in LDS, lane-per-candidate sums
   else { ix.exact = 0; choose_point_layout(ix.dbytes, &ix.lpc, &ix.nch); }
   return PANN_OK;

@@ -43,6 +43,9 @@ namespace pann {
 #ifndef PANN_MINWAVES
 #define PANN_MINWAVES 1
 #endif
+#ifndef PANN_B64_PREFETCH
+#define PANN_B64_PREFETCH 1   /* speculative adjacency-row fetch in the beam-64 kernel (0: A/B library builds) */
+#endif
 #ifndef PANN_MINWAVES_B64
 #define PANN_MINWAVES_B64 7   /* at least 7 waves per SIMD (<= 72 VGPRs); the kernel uses 61 -> 8 waves, LDS caps a CU at 30 queries */
 #endif
@@ -556,6 +559,7 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES_B64) beam_search_b64_
     PANN_WSYNC();
   }
 
+  uint32_t pref_id = SENTINEL, pref_row = SENTINEL;            // speculative row fetch (see the loop)
   bool first = true;
   for (;;) {
     bool do_merge = first;
@@ -581,11 +585,31 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES_B64) beam_search_b64_
       uint32_t cutoff_ord = BIG_ORD;                             // :150-152
       if (f == beam) cutoff_ord = (uint32_t)(readlane64(fkey, (int)f - 1) >> 32);
 
+      // Speculative adjacency-row fetch: the frontier's NEXT unvisited entry is the next vertex unless this iteration's
+      // merge puts something in front of it (hit rate ~80 %), so its row is requested now, a whole iteration ahead -- one
+      // dependent memory round trip less per iteration, which is what a query costs once the chip is no longer full (the
+      // tail of a 10K-query launch).  The load is issued by hand (asm): hipcc drains vmcnt(0) at loop headers, which made a
+      // compiler-visible prefetch wait at once (round 1: -2..-8 %).  An unknown older load only makes the compiler's
+      // counted waits wait for more, never less; the register is drained (vmcnt(0), free by then) before it is reused.
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(pref_row));
+      const bool pref_hit = PANN_B64_PREFETCH && (pref_id == cur);
+      const uint32_t pref_val = pref_row;
+      pref_id = SENTINEL;
+      if (PANN_B64_PREFETCH) {
+        const uint64_t rest = um & (um - 1);
+        if (rest) {
+          pref_id = key_id(readlane64(fkey, __ffsll((unsigned long long)rest) - 1));
+          const uint32_t* np = P.graph + (size_t)pref_id * P.gstride + min((uint32_t)lane, P.gstride - 1);
+          asm volatile("global_load_dword %0, %1, off" : "=v"(pref_row) : "v"(np));
+        }
+      }
+
       const uint32_t* row = P.graph + (size_t)cur * P.gstride;
       for (uint32_t i0 = 0; i0 < P.gstride; i0 += PANN_WAVE) {
         const uint32_t i = i0 + lane;
         uint32_t a = SENTINEL;
-        if (i < P.gstride) a = row[i];
+        if (i0 == 0 && pref_hit) { if (i < P.gstride) a = pref_val; }
+        else if (i < P.gstride) a = row[i];
         const bool act = (a != SENTINEL) && (i < P.degree_limit);
         const uint64_t am = __ballot(act);
         PANN_STAMP(1);
@@ -681,6 +705,7 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES_B64) beam_search_b64_
     PANN_STAMP(4);
     first = false;
   }
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(pref_row));          // no speculative load may outlive its register
 
   const size_t qo = (size_t)qi * P.out.out_k;
   if (lane < (int)P.out.out_k) {                                 // out_k <= beam <= 64
@@ -1142,6 +1167,7 @@ int launch_beam_search(const DeviceIndex& ix, const SearchArgs& a, void* ws, siz
   PANN_DISPATCH(PANN_I8, PANN_L2) PANN_DISPATCH(PANN_I8, PANN_MIPS)
   PANN_DISPATCH(PANN_F32, PANN_L2) PANN_DISPATCH(PANN_F32, PANN_MIPS)
   PANN_DISPATCH(PANN_F16, PANN_L2) PANN_DISPATCH(PANN_F16, PANN_MIPS)
+  PANN_DISPATCH(PANN_BF16, PANN_L2) PANN_DISPATCH(PANN_BF16, PANN_MIPS)
 #undef PANN_DISPATCH
   if (e != hipSuccess) return hip_fail(e, "beam_search_kernel launch");
   // the status word follows the results on the launch stream (pann_search_out::status, device pointer here)

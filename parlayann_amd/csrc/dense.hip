@@ -317,9 +317,12 @@ __global__ void __launch_bounds__(256) dense_topk_kernel(DenseArgs A) {
 // product and partial sum is exact, so the result is bit-identical to the VALU path; on real-valued
 // data the norm form differs from sum((a-b)^2) by cancellation error (DESIGN.md "float order").
 typedef _Float16 mf_half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 mf_bf8 __attribute__((ext_vector_type(8)));
 typedef float mf_float4 __attribute__((ext_vector_type(4)));
 
-template <int METRIC>
+// BF == false: IEEE binary16 operands (v_mfma_f32_16x16x32_f16); BF == true: bfloat16 (v_mfma_f32_16x16x32_bf16).
+// Both accumulate in f32; products of two-byte values are exact in f32, so integer-valued data gives exact sums.
+template <int METRIC, bool BF>
 __global__ void __launch_bounds__(256) dense_topk_mfma_f16_kernel(DenseArgs A) {
   extern __shared__ __align__(16) uint8_t smem[];
   uint8_t* At = smem;                                   // [64][DT_BSTRIDE]
@@ -370,10 +373,16 @@ __global__ void __launch_bounds__(256) dense_topk_mfma_f16_kernel(DenseArgs A) {
         }
       }
       *reinterpret_cast<uint4*>(dst + (size_t)r * DT_BSTRIDE + c * 16) = v;
-      mf_half8 h; __builtin_memcpy(&h, &v, 16);
       float ss = 0.f;
+      if constexpr (BF) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int i = 0; i < 8; i++) { const float f = (float)h[i]; ss = fmaf(f, f, ss); }
+        for (int i = 0; i < 4; i++) { const float lo = bf16_lo(w[i]), hi = bf16_hi(w[i]); ss = fmaf(lo, lo, ss); ss = fmaf(hi, hi, ss); }
+      } else {
+        mf_half8 h; __builtin_memcpy(&h, &v, 16);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const float f = (float)h[i]; ss = fmaf(f, f, ss); }
+      }
       ss = group_sum<16>(ss);                       // the 16 threads of a row are 16 consecutive lanes
       if (c == 0) norms[r] += ss;
     }
@@ -405,11 +414,20 @@ __global__ void __launch_bounds__(256) dense_topk_mfma_f16_kernel(DenseArgs A) {
       const uint32_t ksteps = min((uint32_t)DT_SEG, A.pstride - sg * DT_SEG) / 64;   // 32 halves per MFMA
       for (uint32_t ks = 0; ks < ksteps; ks++) {
         const uint32_t koff = ks * 64 + (lane >> 4) * 16;                              // k = 8*(lane>>4) + j
-        const mf_half8 af = *reinterpret_cast<const mf_half8*>(At + (size_t)(wave * DT_AW + (lane & 15)) * DT_BSTRIDE + koff);
+        if constexpr (BF) {
+          const mf_bf8 af = *reinterpret_cast<const mf_bf8*>(At + (size_t)(wave * DT_AW + (lane & 15)) * DT_BSTRIDE + koff);
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-          const mf_half8 bf = *reinterpret_cast<const mf_half8*>(Bt + (size_t)(t * 16 + (lane & 15)) * DT_BSTRIDE + koff);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[t], 0, 0, 0);
+          for (int t = 0; t < 4; t++) {
+            const mf_bf8 bf = *reinterpret_cast<const mf_bf8*>(Bt + (size_t)(t * 16 + (lane & 15)) * DT_BSTRIDE + koff);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[t], 0, 0, 0);
+          }
+        } else {
+          const mf_half8 af = *reinterpret_cast<const mf_half8*>(At + (size_t)(wave * DT_AW + (lane & 15)) * DT_BSTRIDE + koff);
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            const mf_half8 bf = *reinterpret_cast<const mf_half8*>(Bt + (size_t)(t * 16 + (lane & 15)) * DT_BSTRIDE + koff);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[t], 0, 0, 0);
+          }
         }
       }
     }
@@ -582,17 +600,20 @@ int dense_topk_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, const u
   else if (ix.dtype == PANN_I8) CALL_DENSE(PANN_I8, PANN_MIPS);
   else if (ix.dtype == PANN_F32 && ix.metric == PANN_L2) CALL_DENSE(PANN_F32, PANN_L2);
   else if (ix.dtype == PANN_F32) CALL_DENSE(PANN_F32, PANN_MIPS);
-  else if (ix.exact && ix.metric == PANN_L2) CALL_DENSE(PANN_F16, PANN_L2);      // exact order: VALU path, not MFMA
-  else if (ix.exact) CALL_DENSE(PANN_F16, PANN_MIPS);
+  else if (ix.dtype == PANN_F16 && ix.exact && ix.metric == PANN_L2) CALL_DENSE(PANN_F16, PANN_L2);      // exact order: VALU path, not MFMA
+  else if (ix.dtype == PANN_F16 && ix.exact) CALL_DENSE(PANN_F16, PANN_MIPS);
+  else if (ix.dtype == PANN_BF16 && ix.exact && ix.metric == PANN_L2) CALL_DENSE(PANN_BF16, PANN_L2);
+  else if (ix.dtype == PANN_BF16 && ix.exact) CALL_DENSE(PANN_BF16, PANN_MIPS);
   else {
     const size_t lds2 = (size_t)(DT_A + DT_B) * DT_BSTRIDE + (DT_A + DT_B) * 8 + (size_t)DT_A * mcap * 8;
-#define CALL_MFMA(MT)                                                                                   \
+#define CALL_MFMA(MT, BF)                                                                               \
   do {                                                                                                   \
-    auto kern = dense_topk_mfma_f16_kernel<MT>;                                                          \
+    auto kern = dense_topk_mfma_f16_kernel<MT, BF>;                                                      \
     if (lds2 > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds2, st, A);                                              \
   } while (0)
-    if (ix.metric == PANN_L2) CALL_MFMA(PANN_L2); else CALL_MFMA(PANN_MIPS);
+    if (ix.dtype == PANN_BF16) { if (ix.metric == PANN_L2) CALL_MFMA(PANN_L2, true); else CALL_MFMA(PANN_MIPS, true); }
+    else { if (ix.metric == PANN_L2) CALL_MFMA(PANN_L2, false); else CALL_MFMA(PANN_MIPS, false); }
 #undef CALL_MFMA
   }
 #undef CALL_DENSE

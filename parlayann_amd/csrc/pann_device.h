@@ -94,16 +94,23 @@ template <> struct QReg<PANN_U8>  { uint4 raw; uint32_t qq; };   // qq = sum of 
 template <> struct QReg<PANN_I8>  { uint4 raw; uint32_t qq; };
 template <> struct QReg<PANN_F32> { float f[4]; };
 template <> struct QReg<PANN_F16> { uint4 raw; };        // halves stay packed; widened inside v_fma_mix
+template <> struct QReg<PANN_BF16> { float f[8]; };      // widened once per query (a shift / a mask per element)
 
 template <int DT> struct Acc;           // per-lane partial state
 template <> struct Acc<PANN_U8>  { uint32_t aa, aq; __device__ __forceinline__ void clear() { aa = 0; aq = 0; } };
 template <> struct Acc<PANN_I8>  { int aa, aq;      __device__ __forceinline__ void clear() { aa = 0; aq = 0; } };
 template <> struct Acc<PANN_F32> { float2v s;       __device__ __forceinline__ void clear() { s = float2v{0.f, 0.f}; } };
 template <> struct Acc<PANN_F16> { float2v s;       __device__ __forceinline__ void clear() { s = float2v{0.f, 0.f}; } };
+template <> struct Acc<PANN_BF16> { float2v s;      __device__ __forceinline__ void clear() { s = float2v{0.f, 0.f}; } };
 
 template <int DT> struct AccT { using type = int; };             // type that crosses lanes
 template <> struct AccT<PANN_F32> { using type = float; };
 template <> struct AccT<PANN_F16> { using type = float; };
+template <> struct AccT<PANN_BF16> { using type = float; };
+
+// bfloat16 pair in a dword -> the two floats (exact: the 16 bits are the float's upper half)
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
 
 template <int DT>
 __device__ __forceinline__ QReg<DT> make_qreg(const uint4& q) {
@@ -124,6 +131,10 @@ __device__ __forceinline__ QReg<DT> make_qreg(const uint4& q) {
   } else if constexpr (DT == PANN_F32) {
     r.f[0] = __uint_as_float(q.x); r.f[1] = __uint_as_float(q.y);
     r.f[2] = __uint_as_float(q.z); r.f[3] = __uint_as_float(q.w);
+  } else if constexpr (DT == PANN_BF16) {
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) { r.f[2 * i] = bf16_lo(w[i]); r.f[2 * i + 1] = bf16_hi(w[i]); }
   } else {
     r.raw = q;
   }
@@ -190,6 +201,14 @@ __device__ __forceinline__ void dist_accum(Acc<DT>& acc, const uint4& a, const Q
     } else {
       acc.s = __builtin_elementwise_fma(q01, a01, acc.s);
       acc.s = __builtin_elementwise_fma(q23, a23, acc.s);
+    }
+  } else if constexpr (DT == PANN_BF16) {   // widened by a shift / a mask (exact), arithmetic is f32: even / odd elements in s.x / s.y
+    const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const float2v av{bf16_lo(w[i]), bf16_hi(w[i])}, qv{q.f[2 * i], q.f[2 * i + 1]};
+      if constexpr (METRIC == PANN_L2) { const float2v t = qv - av; acc.s = __builtin_elementwise_fma(t, t, acc.s); }
+      else acc.s = __builtin_elementwise_fma(qv, av, acc.s);
     }
   } else {  // PANN_F16: halves widened to f32 inside the FMA (exact), arithmetic is f32
     const uint32_t w[4] = {a.x, a.y, a.z, a.w}, qw[4] = {q.raw.x, q.raw.y, q.raw.z, q.raw.w};
@@ -271,9 +290,18 @@ __device__ __forceinline__ void dist_accum_exact(float& acc, const uint4& a, con
       if constexpr (METRIC == PANN_L2) { const float t = qf - af; const float p = t * t; acc = acc + p; }
       else { const float p = qf * af; acc = acc + p; }
     }
+  } else if constexpr (DT == PANN_BF16) {
+    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, qw[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const float af = (i & 1) ? bf16_hi(aw[i >> 1]) : bf16_lo(aw[i >> 1]);
+      const float qf = (i & 1) ? bf16_hi(qw[i >> 1]) : bf16_lo(qw[i >> 1]);
+      if constexpr (METRIC == PANN_L2) { const float t = qf - af; const float p = t * t; acc = acc + p; }
+      else { const float p = qf * af; acc = acc + p; }
+    }
   }
 }
-template <int DT> constexpr bool is_float_dt() { return DT == PANN_F32 || DT == PANN_F16; }
+template <int DT> constexpr bool is_float_dt() { return DT == PANN_F32 || DT == PANN_F16 || DT == PANN_BF16; }
 
 
 // one iteration of the gather: U groups of G = 64/LPC candidates starting at Pl[s0]
@@ -518,7 +546,9 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t m, int lane) {
     else if ((ix).dtype == PANN_F32 && (ix).metric == PANN_L2) PANN_LAYOUT_SWITCH(ix, PANN_F32, PANN_L2, CALL);  \
     else if ((ix).dtype == PANN_F32 && (ix).metric == PANN_MIPS) PANN_LAYOUT_SWITCH(ix, PANN_F32, PANN_MIPS, CALL); \
     else if ((ix).dtype == PANN_F16 && (ix).metric == PANN_L2) PANN_LAYOUT_SWITCH(ix, PANN_F16, PANN_L2, CALL);  \
-    else PANN_LAYOUT_SWITCH(ix, PANN_F16, PANN_MIPS, CALL);                                     \
+    else if ((ix).dtype == PANN_F16) PANN_LAYOUT_SWITCH(ix, PANN_F16, PANN_MIPS, CALL);         \
+    else if ((ix).metric == PANN_L2) PANN_LAYOUT_SWITCH(ix, PANN_BF16, PANN_L2, CALL);          \
+    else PANN_LAYOUT_SWITCH(ix, PANN_BF16, PANN_MIPS, CALL);                                    \
   } while (0)
 
 }  // namespace pann

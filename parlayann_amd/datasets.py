@@ -6,6 +6,13 @@ distances in any summation order (all partial sums are integers < 2**24).
 """
 import numpy as np
 
+from .bf16 import bfloat16, to_bf16
+
+
+def _cast(x, dtype):
+    """astype that also knows the bfloat16 stand-in dtype"""
+    return to_bf16(x) if np.dtype(dtype) == bfloat16 else x.astype(dtype)
+
 
 def _mixture(n, d, seed, n_centers, rank, center_scale, basis_scale, noise_scale, centers_seed=1234):
     crng = np.random.default_rng(centers_seed)          # cluster geometry shared by base and queries
@@ -28,7 +35,7 @@ def sift_like(n, d=128, seed=1234, dtype=np.uint8, n_centers=256, rank=16):
     """Integer-valued SIFT-shaped vectors in [0,255] as uint8 / float32 / float16."""
     x = _mixture(n, d, seed, n_centers, rank, center_scale=22.0, basis_scale=9.0, noise_scale=12.0)
     x = np.clip(np.rint(x + 100.0), 0, 255)
-    return x.astype(dtype)
+    return _cast(x, dtype)
 
 
 def sift1m_like(n, d=128, seed=1234, dtype=np.float16):
@@ -38,7 +45,7 @@ def sift1m_like(n, d=128, seed=1234, dtype=np.float16):
     `sift_like` (rank 16) is easier (recall 0.9997) and stays the generator of the unit tests."""
     x = _mixture(n, d, seed, 256, 32, center_scale=22.0, basis_scale=9.0, noise_scale=14.0)
     x = np.clip(np.rint(x + 100.0), 0, 255)
-    return x.astype(dtype)
+    return _cast(x, dtype)
 
 
 def deep_like(n, d=96, seed=1234, n_centers=256, rank=16):

@@ -31,6 +31,8 @@ extern "C" int pann_host_hcnng_build(const void* pts, uint64_t n, uint32_t d, in
   if (dtype == PANN_F32 && metric == PANN_MIPS) GO(float, PANN_MIPS);
   if (dtype == PANN_F16 && metric == PANN_L2) GO(half_t, PANN_L2);
   if (dtype == PANN_F16 && metric == PANN_MIPS) GO(half_t, PANN_MIPS);
+  if (dtype == PANN_BF16 && metric == PANN_L2) GO(bf16_t, PANN_L2);
+  if (dtype == PANN_BF16 && metric == PANN_MIPS) GO(bf16_t, PANN_MIPS);
 #undef GO
   return 1;
 }

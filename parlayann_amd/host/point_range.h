@@ -20,6 +20,8 @@ template <> struct pann_dtype_of<int8_t> { static constexpr int value = PANN_I8;
 template <> struct pann_dtype_of<float> { static constexpr int value = PANN_F32; };
 struct half_t { uint16_t bits; };   // storage-only fp16 (this build's extension)
 template <> struct pann_dtype_of<half_t> { static constexpr int value = PANN_F16; };
+struct bf16_t { uint16_t bits; };   // storage-only bfloat16 (this build's extension)
+template <> struct pann_dtype_of<bf16_t> { static constexpr int value = PANN_BF16; };
 
 template <typename T_, int METRIC>
 struct Point_ {

@@ -8,11 +8,12 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import (PANN_F16, PANN_F32, PANN_I8, PANN_L2, PANN_MIPS, PANN_U8, BuildStats, QueryParams, SearchOut,
+from ._capi import (PANN_BF16, PANN_F16, PANN_F32, PANN_I8, PANN_L2, PANN_MIPS, PANN_U8, BuildStats, QueryParams, SearchOut,
                     check)
+from .bf16 import bfloat16
 
 _DT = {np.dtype(np.uint8): PANN_U8, np.dtype(np.int8): PANN_I8, np.dtype(np.float32): PANN_F32,
-       np.dtype(np.float16): PANN_F16}
+       np.dtype(np.float16): PANN_F16, bfloat16: PANN_BF16}
 
 
 def dtype_code(dt):
@@ -49,7 +50,7 @@ class DeviceIndex:
         lib = _capi.load()
         points = np.ascontiguousarray(points)
         if points.ndim != 2 or points.dtype not in _DT:
-            raise ValueError("points must be a 2-D uint8/int8/float32/float16 array")
+            raise ValueError("points must be a 2-D uint8/int8/float32/float16/bfloat16 (parlayann_amd.bfloat16) array")
         n, d = points.shape
         if graph is not None:
             graph = np.ascontiguousarray(graph, dtype=np.uint32)

@@ -10,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB = os.path.join(ORACLE_DIR, "libpann_oracle.so")
 
-DT = {np.dtype(np.uint8): 0, np.dtype(np.int8): 1, np.dtype(np.float32): 2, np.dtype(np.float16): 3}
+DT = {np.dtype(np.uint8): 0, np.dtype(np.int8): 1, np.dtype(np.float32): 2, np.dtype(np.float16): 3,
+      np.dtype([("bf16", np.uint16)]): 4}          # parlayann_amd.bfloat16 (numpy has no bfloat16)
 METRIC = {"l2": 0, "euclidian": 0, "mips": 1, 0: 0, 1: 1}
 
 _lib = None

@@ -115,3 +115,22 @@ def test_build_schedule_and_recall_file_formats(oracle):
     gt = np.array([[1, 2, 3, 4]], np.uint32); gd = np.array([[1.0, 2.0, 2.0, 3.0]], np.float32)
     assert oracle.recall(np.array([[1, 3]], np.uint32), gt, gd, 2) == 1.0   # 3 ties with the 2nd
     assert oracle.recall(np.array([[1, 4]], np.uint32), gt, gd, 2) == 0.5
+
+
+def test_bf16_conversion_and_oracle_distance(oracle):
+    """parlayann_amd.bfloat16: round-to-nearest-even from f32, exact widening back; the oracle's bf16 distance is the f32 rule
+    on the widened values"""
+    from parlayann_amd import bfloat16, from_bf16, to_bf16
+    x = np.array([0.0, 1.0, -2.5, 255.0, 256.0, 257.0, 1e-3, 3.1415927, -65504.0], np.float32)
+    b = to_bf16(x)
+    assert b.dtype == bfloat16 and b.itemsize == 2
+    back = from_bf16(b)
+    assert back[3] == 255.0 and back[4] == 256.0 and back[5] in (256.0, 258.0)          # 8 significant bits
+    assert np.all(np.abs(back - x) <= np.abs(x) * 2.0 ** -8)
+    np.testing.assert_array_equal(to_bf16(back).view(np.uint16), b.view(np.uint16))     # idempotent
+    rng = np.random.default_rng(0)
+    A = to_bf16(rng.integers(0, 256, (4, 64)).astype(np.float32)); B = to_bf16(rng.integers(0, 256, (4, 64)).astype(np.float32))
+    for i in range(4):
+        a, c = from_bf16(A[i]).astype(np.float64), from_bf16(B[i]).astype(np.float64)
+        assert oracle.distance(A[i], B[i], "l2") == np.float32(((a - c) ** 2).sum())
+        assert oracle.distance(A[i], B[i], "mips") == np.float32(-(a * c).sum())
