@@ -120,6 +120,9 @@ float distance(int dtype, int metric, const void* pa, const void* pb, unsigned d
   return -r;
 }
 
+// diagnostic counters (tools/ only): iterations that skipped the merge (:162-168) / merges, summed over all searches
+static std::atomic<uint64_t> g_dbg_skips{0}, g_dbg_merges{0};
+
 struct IdDist { uint32_t id; float dist; };
 // total order used everywhere: beamSearch.h:46-48, vamana/index.h:80-82
 inline bool less_id_dist(const IdDist& a, const IdDist& b) {
@@ -216,6 +219,7 @@ void beam_search(const Dataset& D, const void* q, int64_t self_id, const uint32_
     if (cand.empty() ||
         (QP.limit >= 2 * (int64_t)beam && (int64_t)cand.size() < beam / 8 && offset + 1 < remain)) {
       offset++;
+      g_dbg_skips.fetch_add(1, std::memory_order_relaxed);
       continue;
     }
     offset = 0;
@@ -226,6 +230,7 @@ void beam_search(const Dataset& D, const void* q, int64_t self_id, const uint32_
     size_t msize = std::set_union(frontier.begin(), frontier.end(), cand.begin(), cend,
                                   merged.begin(), less_id_dist) - merged.begin();  // :178-181
     cand.clear();
+    g_dbg_merges.fetch_add(1, std::memory_order_relaxed);
     msize = std::min<size_t>((size_t)beam, msize);  // :185
 
     if (QP.k > 0 && (int64_t)msize > QP.k && D.metric == M_L2) {  // :190 (is_metric(): L2 only)
@@ -310,6 +315,11 @@ inline uint64_t splitmix64(uint64_t& s) {
 }  // namespace
 
 extern "C" {
+
+void pann_oracle_debug_counters(uint64_t* out2, int reset) {
+  out2[0] = g_dbg_skips.load(); out2[1] = g_dbg_merges.load();
+  if (reset) { g_dbg_skips = 0; g_dbg_merges = 0; }
+}
 
 int pann_oracle_hw_threads(void) { return (int)std::thread::hardware_concurrency(); }
 

@@ -43,6 +43,14 @@ namespace pann {
 #ifndef PANN_MINWAVES
 #define PANN_MINWAVES 1
 #endif
+#ifndef PANN_B128_PAIR
+/* beam 65..128: two vertices per memory round trip while merges are skipped.  Exact (the whole GPU suite and the fuzz soak pass
+   with it on) but OFF: measured on the C3-shaped 2M build, search phase 0.864 s without vs 0.91..0.93 s with it -- the kernel
+   already moves 5.1 TB/s on the HBM side (81 % of the 6.3 TB/s random-row ceiling), so more bytes in flight buy nothing and the
+   rows fetched for nothing when row 1 ends the skipping cost bandwidth.  It does pay when the table sits wholly in LDS and
+   occupancy is low (PANN_B128_SPLIT=3: 1.03 -> 0.98 s), which is slower than the default split anyway. */
+#define PANN_B128_PAIR 0
+#endif
 #ifndef PANN_B64_PREFETCH
 #define PANN_B64_PREFETCH 1   /* speculative adjacency-row fetch in the beam-64 kernel (0: A/B library builds) */
 #endif
@@ -130,8 +138,9 @@ __device__ __forceinline__ uint32_t lower_bound_lds(const uint64_t* A, uint32_t 
 // Split mode (HBM branch, hb = 1 or 2): the slots whose low hb bits are all ones live in HBM (index s >> hb), the
 // other half / three quarters in LDS right after T -- fewer single-word L2 requests per row for a smaller LDS
 // footprint than the whole table.
+// hb == 3: the WHOLE table in LDS as 24-bit planes (12 KB at beam 128) -- no table traffic to HBM at all
 __device__ __forceinline__ uint32_t split_lds_index(uint32_t s, uint32_t hb) {
-  return hb == 1 ? (s >> 1) : (s >> 2) * 3 + (s & 3);
+  return hb == 1 ? (s >> 1) : hb == 3 ? s : (s >> 2) * 3 + (s & 3);
 }
 // Planar 24-bit entries (p24 != 0: n < 2^24 - 1, the LDS part only): a low plane of uint16 followed by a high plane of uint8,
 // 3 bytes per slot instead of 4 -- exact (an id IS 24 bits), and 2 KB less LDS per query at beam 65..128.
@@ -162,13 +171,28 @@ __device__ __forceinline__ void lds_part_clear(const LdsPart& L, int lane) {
   }
 }
 
+// What one filter_update call changed, per lane: enough to put the table back (a row that was scanned speculatively and
+// turns out not to be the next vertex must leave no trace in the lossy table, whose state decides later hits and misses).
+struct FilterUndo { uint32_t s, old; bool wrote; };
+template <bool HASH_LDS>
+__device__ __forceinline__ void filter_undo(uint32_t* H, const FilterUndo& u, uint32_t hb, const LdsPart& Lp) {
+  if (u.wrote) {
+    const uint32_t hm = (1u << hb) - 1u;
+    if constexpr (HASH_LDS) H[u.s] = u.old;
+    else if (hb != 3 && (u.s & hm) == hm) __hip_atomic_store(H + (u.s >> hb), u.old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else lds_part_store(Lp, split_lds_index(u.s, hb), u.old);
+  }
+  PANN_WSYNC();
+}
+
 template <bool HASH_LDS>
 __device__ __forceinline__ bool filter_update(uint32_t* H, uint32_t hmask, bool active, uint32_t a, int lane,
-                                              uint8_t* T = nullptr, uint32_t hb = 0, LdsPart Lp = LdsPart{nullptr, 0, 0}) {
+                                              uint8_t* T = nullptr, uint32_t hb = 0, LdsPart Lp = LdsPart{nullptr, 0, 0},
+                                              FilterUndo* undo = nullptr) {
   const uint32_t s = (uint32_t)hash64_2((uint64_t)a) & hmask;
   uint32_t old, w;
   const uint32_t hm = (1u << hb) - 1u;
-  const bool in_hbm = (s & hm) == hm;                                   // always true when hb == 0
+  const bool in_hbm = hb != 3 && (s & hm) == hm;                        // always true when hb == 0, never when hb == 3
   if constexpr (HASH_LDS) {
     old = active ? H[s] : 0u;
     PANN_WSYNC();
@@ -200,6 +224,7 @@ __device__ __forceinline__ bool filter_update(uint32_t* H, uint32_t hmask, bool 
   }
   const uint32_t a_prev = __shfl(a, prev < 0 ? lane : prev);
   const bool seen = active && (prev >= 0 ? (a_prev == a) : (old == a));
+  if (undo) { undo->s = s; undo->old = old; undo->wrote = active && last; }   // `old` of a slot group: the value on entry
   if constexpr (HASH_LDS) {
     PANN_WSYNC();
     if (active && last) H[s] = a;
@@ -242,6 +267,27 @@ __device__ __forceinline__ uint32_t gather_distances(const BSParams& P, const QR
         c += __popcll(pm);
       });
   }
+  return c;
+}
+
+// The same for the survivors of TWO rows listed one after the other in Pl (row 1: Pl[0..split), row 2: the rest):
+// *c_split = size of C after the candidates of row 1 alone (the appends keep Pl order).
+template <int DT, int METRIC, int LPC, bool NCH1, int U>
+__device__ __forceinline__ uint32_t gather_distances_split(const BSParams& P, const QReg<DT>& qreg, const uint4* qlds,
+                                                           const uint32_t* Pl, uint32_t m, uint32_t split, uint32_t cutoff_ord,
+                                                           uint64_t* C, uint32_t c, int lane, uint32_t* c_split) {
+  const PointsView PV{P.points, P.pstride, P.nch, P.exact};
+  uint32_t c1 = c;
+  gather_tile<DT, METRIC, LPC, NCH1, U>(PV, qreg, qlds, Pl, m, lane,
+    [&](bool has, uint32_t ci, uint32_t id, float dist) {
+      const uint32_t ord = f2ord(dist);
+      const bool pass = has && (ord < cutoff_ord);
+      const uint64_t pm = __ballot(pass);
+      if (pass) C[c + lanes_below(pm, lane)] = ((uint64_t)ord << 32) | id;
+      c += __popcll(pm);
+      c1 += __popcll(__ballot(pass && ci < split));
+    });
+  *c_split = c1;
   return c;
 }
 
@@ -745,7 +791,7 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
   const uint32_t hsize = 1u << P.bits, hmask = hsize - 1u;
   const uint32_t beam = P.beam;
   const uint32_t BIG_ORD = f2ord(2147483648.0f);
-  const LdsPart Lp{reinterpret_cast<uint8_t*>(Hl), HASH_LDS ? 0u : (P.hsplit ? hsize - (hsize >> P.hsplit) : 0u), P.p24};
+  const LdsPart Lp{reinterpret_cast<uint8_t*>(Hl), HASH_LDS ? 0u : (P.hsplit == 3 ? hsize : P.hsplit ? hsize - (hsize >> P.hsplit) : 0u), P.p24};
   // filter in LDS: one query per block.  Filter in HBM (16 KB of LDS would cap a CU at 8 queries): persistent
   // blocks, one table per block, queries pulled from a counter.
   uint32_t qi = blockIdx.x;
@@ -757,7 +803,7 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
   while (qi < P.nq) {
   uint32_t* H = HASH_LDS ? Hl : P.hash_global + ((size_t)blockIdx.x << P.bits);
   const uint32_t hb = HASH_LDS ? 0u : P.hsplit;
-  for (uint32_t i = lane; i < (hsize >> hb); i += PANN_WAVE) hstore<HASH_LDS>(H, i, SENTINEL);
+  if (hb != 3) for (uint32_t i = lane; i < (hsize >> hb); i += PANN_WAVE) hstore<HASH_LDS>(H, i, SENTINEL);
   if (hb) lds_part_clear(Lp, lane);
   const int64_t self = P.query_ids ? (int64_t)P.query_ids[qi] : -1;
   const uint8_t* qrow = P.query_ids ? P.points + (uint64_t)self * P.pstride : P.queries + (uint64_t)qi * P.qstride;
@@ -802,6 +848,73 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
       PANN_STAMP(0);
       const uint64_t cur_key = entry_key((uint32_t)cur_idx);
       const uint32_t cur = key_id(cur_key);
+      // ---- two vertices per memory round trip.  While merges are being skipped (:162-168: fewer than beam/8 candidates
+      // and another unvisited entry) the frontier and the cutoff do not change, so the vertex after `cur` is already known:
+      // the second unvisited entry.  83 % of the builder's iterations skip (66 % of beam-64 queries), so both adjacency
+      // rows are fetched together, the filter is replayed row after row (row 2 sees row 1's updates, as in the
+      // sequential loop) and ONE gather fetches the survivors of both -- twice the bytes in flight per wave in the phase
+      // that is 52 % of this kernel's time.  If the candidates of row 1 alone end the skipping (or row 2 does not fit),
+      // row 2 never happened: its candidates are cut off the list and its table writes are put back (FilterUndo).
+      if (PANN_B128_PAIR && P.skip_enabled && more_unvisited && P.gstride <= PANN_WAVE && nvis + 1 < P.limit) {
+        uint64_t r0 = um0, r1 = um1;
+        if (r0) r0 &= r0 - 1; else r1 &= r1 - 1;
+        const int idx2 = r0 ? __ffsll((unsigned long long)r0) - 1 : 64 + __ffsll((unsigned long long)r1) - 1;
+        if (r0) r0 &= r0 - 1; else r1 &= r1 - 1;
+        const bool more_after2 = (r0 | r1) != 0ull;
+        const uint64_t key2 = entry_key((uint32_t)idx2);
+        const uint32_t cur2 = key_id(key2);
+        uint32_t cutoff2 = BIG_ORD;
+        if (f == beam) cutoff2 = (uint32_t)(entry_key(f - 1) >> 32);
+        uint32_t a1 = SENTINEL, a2 = SENTINEL;
+        if (lane < (int)P.gstride) {
+          a1 = (pref_id == cur) ? pref_row : P.graph[(size_t)cur * P.gstride + lane];
+          a2 = P.graph[(size_t)cur2 * P.gstride + lane];
+        }
+        pref_id = SENTINEL;
+        const bool act1 = (a1 != SENTINEL) && ((uint32_t)lane < P.degree_limit);
+        const bool act2 = (a2 != SENTINEL) && ((uint32_t)lane < P.degree_limit);
+        const bool seen1 = filter_update<HASH_LDS>(H, hmask, act1, a1, lane, T, hb, Lp);
+        FilterUndo u2;
+        const bool seen2 = filter_update<HASH_LDS>(H, hmask, act2, a2, lane, T, hb, Lp, &u2);
+        const bool keep1 = act1 && !seen1 && ((int64_t)a1 != self);
+        const bool keep2 = act2 && !seen2 && ((int64_t)a2 != self);
+        const uint64_t km1 = __ballot(keep1), km2 = __ballot(keep2);
+        const uint32_t m1 = __popcll(km1), m2 = __popcll(km2);
+        const bool both = (c + m1 + m2 <= P.ccap);                     // the candidate list is sized for beam/8 - 1 + ONE row
+        if (keep1) Pl[lanes_below(km1, lane)] = a1;
+        if (both && keep2) Pl[m1 + lanes_below(km2, lane)] = a2;
+        PANN_WSYNC();
+        uint32_t c_after1 = c;
+        if (both) {
+          if (m1 + m2) c = gather_distances_split<DT, METRIC, LPC, NCH1, PANN_GU_B128(LPC, NCH1)>(P, qreg, qlds, Pl, m1 + m2, m1, cutoff2, C, c, lane, &c_after1);
+        } else {
+          if (m1) c = gather_distances<DT, METRIC, LPC, NCH1, PANN_GU_B128(LPC, NCH1), false>(P, qreg, qlds, Pl, m1, cutoff2, C, c, lane);
+          c_after1 = c;
+        }
+        PANN_WSYNC();
+        // the reference's decision after vertex 1 (another unvisited entry exists): skip iff its list is still short
+        const bool two = both && (c_after1 == 0 || c_after1 < beam / 8);
+        if (!two) { c = c_after1; filter_undo<HASH_LDS>(H, u2, hb, Lp); }
+        // commit: visited.insert(current) (:112-114), counters
+        if (cur_idx < 64) { if (lane == cur_idx) fflag[0] = 1; } else { if (lane == cur_idx - 64) fflag[1] = 1; }
+        if (two) { if (idx2 < 64) { if (lane == idx2) fflag[0] = 1; } else { if (lane == idx2 - 64) fflag[1] = 1; } }
+        if (lane == 0 && P.out.visited_cap) {
+          const uint32_t nv = two ? 2u : 1u;
+          if (nvis + nv <= P.out.visited_cap) {
+            const size_t at = (size_t)qi * P.out.visited_cap + nvis;
+            if (P.out.visited_ids) { P.out.visited_ids[at] = cur; if (two) P.out.visited_ids[at + 1] = cur2; }
+            if (P.out.visited_dists) { P.out.visited_dists[at] = key_dist(cur_key); if (two) P.out.visited_dists[at + 1] = key_dist(key2); }
+          } else {
+            atomicOr(P.status, 1u);
+          }
+        }
+        nvis += two ? 2u : 1u;
+        degsum += __popcll(__ballot(act1)) + (two ? __popcll(__ballot(act2)) : 0u);
+        dcmps += m1 + (two ? m2 : 0u);
+        const bool more_left = two ? more_after2 : true;
+        const bool skip = (c == 0) || (c < beam / 8 && more_left);
+        do_merge = !skip;
+      } else {
       if (cur_idx < 64) { if (lane == cur_idx) fflag[0] = 1; } else { if (lane == cur_idx - 64) fflag[1] = 1; }
       if (lane == 0 && P.out.visited_cap) {
         if (nvis < P.out.visited_cap) {
@@ -858,6 +971,7 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
       }
       const bool skip = (c == 0) || (P.skip_enabled && c < beam / 8 && more_unvisited);
       do_merge = !skip;
+      }   // single-vertex path
     }
     if (do_merge) {
       const uint32_t f_old = f;
@@ -1049,12 +1163,14 @@ static Plan make_plan(const DeviceIndex& ix, const SearchArgs& a) {
     if (p.b128_hbm) {   // one table per block, >= the resident waves
       static const char* sp = getenv("PANN_B128_SPLIT");
       p.hsplit = sp ? (uint32_t)atoi(sp) : 1u;     // measured: half in LDS 2.99 M q/s, none 2.46, three quarters 2.67, whole table in LDS 2.28
-      if (p.hsplit > 2) p.hsplit = 0;
-      p.hash_lds = false; p.slots = 256 * 32;
+      if (p.hsplit > 3) p.hsplit = 0;
       static const bool no24 = getenv("PANN_B128_NO24") != nullptr;              // diagnostic A/B switch
+      if (p.hsplit == 3 && (no24 || !(ix.n < 0xFFFFFFull))) p.hsplit = 1;     // the all-LDS mode exists for 24-bit planes only
+      p.hash_lds = false; p.slots = 256 * 32;
       p.p24 = (p.hsplit && ix.n < 0xFFFFFFull && !no24) ? 1u : 0u;
       // the 1 KB replay scratch of filter_update aliases the merge scratch S; the LDS share of the table follows the query
-      hbytes = p.hsplit ? (((size_t)1 << p.bits) - ((size_t)1 << (p.bits - p.hsplit))) * (p.p24 ? 3 : 4) : 0;
+      hbytes = p.hsplit == 3 ? ((size_t)3 << p.bits)
+             : p.hsplit ? (((size_t)1 << p.bits) - ((size_t)1 << (p.bits - p.hsplit))) * (p.p24 ? 3 : 4) : 0;
     }
     p.lds_bytes = (uint32_t)(128 * 8 + (size_t)p.ccap * 8 + 128 + (nch1 ? 0 : (size_t)ix.nch * ix.lpc * 16) + hbytes);
   }
