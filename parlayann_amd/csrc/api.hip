@@ -687,8 +687,23 @@ int pann_bruteforce_knn(pann_index* idx, const void* queries, uint64_t nq, uint6
   if (int rc = idx->stage[7].ensure(nq * k * 4)) return rc;
   PANN_HIP(hipMemcpyAsync(idx->stage[2].p, queries, (nq - 1) * q_stride_bytes + idx->ix.dbytes, hipMemcpyHostToDevice, st));
   const uint32_t ntiles = (uint32_t)((nq + 63) / 64);
-  // enough workgroups to fill 256 CUs a few times over, B pieces of at least 4096 rows
-  uint32_t nsplit = std::max<uint32_t>(1, std::min<uint32_t>((2048 + ntiles - 1) / ntiles, (uint32_t)((idx->ix.n + 4095) / 4096)));
+  // B is cut into nsplit pieces per A tile.  Every piece warms up its own top-k lists (about k * ln(piece / k) + k list inserts per
+  // query: 10K x 1M, k = 100 spent 7.5 G instructions there at 14 pieces), and at k = 100 the lists leave room for ONE workgroup
+  // per CU, so what matters is how evenly ntiles * nsplit workgroups fill whole rounds of the 256 CUs: the smallest count (<= 8,
+  // or enough to reach every CU when there are few queries) with the best fill wins (10K queries: 157 tiles x 3 = 1.84 rounds,
+  // 43 ms; x 1: 53 ms; x 14: 68 ms)
+  uint32_t want = 1;
+  {
+    double best = -1.0;
+    const uint32_t smax = std::max<uint32_t>(8, (256 + ntiles - 1) / ntiles);
+    for (uint32_t sp = 1; sp <= smax; sp++) {
+      const double wgs = (double)ntiles * sp;
+      const double fill = wgs / (256.0 * std::ceil(wgs / 256.0)) - 0.02 * std::min<uint32_t>(sp, 8);
+      if (fill > best + 1e-9) { best = fill; want = sp; }
+    }
+  }
+  const uint32_t env_split = getenv("PANN_GT_NSPLIT") ? (uint32_t)atoi(getenv("PANN_GT_NSPLIT")) : 0u;      // diagnostic A/B switch
+  uint32_t nsplit = std::max<uint32_t>(1, std::min<uint32_t>(env_split ? env_split : want, (uint32_t)((idx->ix.n + 4095) / 4096)));
   nsplit = std::min<uint32_t>(nsplit, 64);
   if (int rc = dense_topk_dev(idx->ix, idx->ws2, st, idx->stage[2].as<uint8_t>(), q_stride_bytes, nullptr, nullptr, nullptr,
                               nullptr, nullptr, nullptr, ntiles, nq, idx->ix.n, nsplit, k, 0, idx->stage[6].as<uint32_t>(),

@@ -393,6 +393,45 @@ __global__ void __launch_bounds__(256) dense_topk_mfma_f16_kernel(DenseArgs A) {
   const uint32_t a_valid = A.a_ids ? A.pstride : A.dbytes;
   if (nseg == 1) stage_rows(At, An, 0, a_rowptr, a_valid, na_tile);
 
+  // register double buffer of the B tile (single-segment rows): thread (r0 = tid >> 4, c = tid & 15) holds chunk c of rows
+  // r0, r0 + 16, r0 + 32, r0 + 48
+  uint4 pre[4];
+  auto load_pre = [&](uint64_t bt, uint32_t nrows) {
+    const int r0 = tid >> 4, c = tid & 15;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int r = r0 + 16 * k;
+      pre[k] = make_uint4(0, 0, 0, 0);
+      if (r < (int)nrows) {
+        const uint64_t id = A.b_ids ? (uint64_t)A.b_ids[bt + r] : (bt + r);
+        pre[k] = load16_guarded(A.points + id * A.pstride, c * 16, A.pstride);
+      }
+    }
+  };
+  auto store_pre = [&](uint32_t nrows) {
+    const int r0 = tid >> 4, c = tid & 15;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int r = r0 + 16 * k;
+      const uint4 v = pre[k];
+      *reinterpret_cast<uint4*>(Bt + (size_t)r * DT_BSTRIDE + c * 16) = v;
+      float ss = 0.f;
+      if constexpr (BF) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const float lo = bf16_lo(w[i]), hi = bf16_hi(w[i]); ss = fmaf(lo, lo, ss); ss = fmaf(hi, hi, ss); }
+      } else {
+        mf_half8 h; __builtin_memcpy(&h, &v, 16);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const float f = (float)h[i]; ss = fmaf(f, f, ss); }
+      }
+      ss = group_sum<16>(ss);
+      if (c == 0) Bn[r] = ss;
+    }
+    (void)nrows;
+  };
+  if (nseg == 1 && bs < be) load_pre(bs, (uint32_t)min((uint64_t)DT_B, be - bs));
+
   for (uint64_t bt = bs; bt < be; bt += DT_B) {
     const uint32_t nb_tile = (uint32_t)min((uint64_t)DT_B, be - bt);
     auto b_rowptr = [&](int r) -> const uint8_t* {
@@ -408,8 +447,16 @@ __global__ void __launch_bounds__(256) dense_topk_mfma_f16_kernel(DenseArgs A) {
     __syncthreads();
     for (uint32_t sg = 0; sg < nseg; sg++) {
       if (sg > 0) __syncthreads();
-      stage_rows(Bt, Bn, sg, b_rowptr, A.pstride, nb_tile);
-      if (nseg > 1) stage_rows(At, An, sg, a_rowptr, a_valid, na_tile);
+      if (nseg == 1) {
+        // rows of one 256-byte segment: this tile's rows were requested while the previous tile was being multiplied
+        // (pre[]), the next tile's are requested now -- with k = 100 the per-row lists leave room for ONE workgroup per CU,
+        // so without this every tile paid a full, exposed HBM round trip (10K x 1M: 50 ms of kernel time, 2/3 of it waiting)
+        store_pre(nb_tile);
+        if (bt + DT_B < be) load_pre(bt + DT_B, (uint32_t)min((uint64_t)DT_B, be - (bt + DT_B)));
+      } else {
+        stage_rows(Bt, Bn, sg, b_rowptr, A.pstride, nb_tile);
+        stage_rows(At, An, sg, a_rowptr, a_valid, na_tile);
+      }
       __syncthreads();
       const uint32_t ksteps = min((uint32_t)DT_SEG, A.pstride - sg * DT_SEG) / 64;   // 32 halves per MFMA
       for (uint32_t ks = 0; ks < ksteps; ks++) {
@@ -468,31 +515,48 @@ __global__ void __launch_bounds__(256) dense_topk_mfma_f16_kernel(DenseArgs A) {
       }
       continue;                                             // the next tile's barrier protects K
     }
+    // m > 16 (ground truth): the 16 distances of a lane (4 rows x 4 columns) are tested against register copies of their rows'
+    // m-th best FIRST -- after the lists have warmed up nearly every tile ends here with one ballot; only a tile with a
+    // survivor walks the (row, column) pairs and inserts (the lists live in LDS, one wave-wide shift per insert)
+    {
+      uint64_t key[4][4];
+      bool pass[4][4];
+      bool any = false;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const uint32_t ar = wave * DT_AW + q * 4 + r;          // this lane's A row for register r
-      const float an = An[ar];
-      uint64_t* mylist = lists + (size_t)ar * A.mcap;
+      for (int r = 0; r < 4; r++) {
+        const uint32_t ar = wave * DT_AW + q * 4 + r;          // this lane's A row for register r
+        const float an = An[ar];
+        const uint64_t tau = (lists + (size_t)ar * A.mcap)[A.m - 1];
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        const uint32_t bc = t * 16 + (lane & 15);
-        const uint32_t bid = Bid[bc];
-        float dist;
-        if constexpr (METRIC == PANN_L2) dist = (an + Bn[bc]) - 2.0f * acc[t][r];
-        else dist = -acc[t][r];
-        const uint64_t key = make_key(dist, bid);
-        bool ok = (bc < nb_tile) && (ar < na_tile);
-        if (A.exclude_same_id) ok = ok && (bid != Aid[ar]);
-        const uint64_t tau = mylist[A.m - 1];
-        uint64_t mask = __ballot(ok && key < tau);
-        while (mask) {                                        // rare after the first tiles
-          const int L = __ffsll((unsigned long long)mask) - 1;
-          const uint32_t klo = __builtin_amdgcn_readlane((uint32_t)key, L);
-          const uint32_t khi = __builtin_amdgcn_readlane((uint32_t)(key >> 32), L);
-          const uint64_t x = ((uint64_t)khi << 32) | klo;
-          mask &= mask - 1;
-          uint64_t* list = lists + (size_t)(wave * DT_AW + (L >> 4) * 4 + r) * A.mcap;
-          if (x < list[A.m - 1]) list_insert(list, A.mcap, x, lane);
+        for (int t = 0; t < 4; t++) {
+          const uint32_t bc = t * 16 + (lane & 15);
+          const uint32_t bid = Bid[bc];
+          float dist;
+          if constexpr (METRIC == PANN_L2) dist = (an + Bn[bc]) - 2.0f * acc[t][r];
+          else dist = -acc[t][r];
+          key[r][t] = make_key(dist, bid);
+          bool ok = (bc < nb_tile) && (ar < na_tile);
+          if (A.exclude_same_id) ok = ok && (bid != Aid[ar]);
+          pass[r][t] = ok && key[r][t] < tau;
+          any = any || pass[r][t];
+        }
+      }
+      if (__any(any)) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            uint64_t mask = __ballot(pass[r][t]);
+            while (mask) {
+              const int L = __ffsll((unsigned long long)mask) - 1;
+              const uint32_t klo = __builtin_amdgcn_readlane((uint32_t)key[r][t], L);
+              const uint32_t khi = __builtin_amdgcn_readlane((uint32_t)(key[r][t] >> 32), L);
+              const uint64_t x = ((uint64_t)khi << 32) | klo;
+              mask &= mask - 1;
+              uint64_t* list = lists + (size_t)(wave * DT_AW + (L >> 4) * 4 + r) * A.mcap;
+              if (x < list[A.m - 1]) list_insert(list, A.mcap, x, lane);
+            }
+          }
         }
       }
     }
