@@ -123,15 +123,39 @@ class DeviceShardedIndex:
     every rank's [nq, k] ids and distances (k * 8 bytes per query per rank) and pann_merge_topk_dev keeps the k smallest
     by (dist, id).  Results stay in HBM (torch tensors)."""
 
-    def __init__(self, points, max_degree, build, device_ordinal=0, metric="Euclidian"):
+    def __init__(self, points, max_degree, build, device_ordinal=0, metric="Euclidian", n_total=None):
+        """points: the whole base (every rank slices its own range out of it), or -- with n_total given -- only this rank's
+        slice [lo, hi) of a base of n_total points (100M-point runs: nobody holds the whole base)"""
         from .index import DeviceIndex
         self.rank, self.world = _world()
-        self.n = len(points)
+        self.n = len(points) if n_total is None else int(n_total)
         self.lo, self.hi = shard_range(self.n, self.rank, self.world)
-        self.ix = DeviceIndex(points[self.lo:self.hi], max_degree=max_degree, device=device_ordinal, metric=metric)
+        shard = points[self.lo:self.hi] if n_total is None else points
+        assert len(shard) == self.hi - self.lo
+        self.ix = DeviceIndex(shard, max_degree=max_degree, device=device_ordinal, metric=metric)
         build(self.ix)
         self.dev = torch.device("cuda", device_ordinal)
         self._starts = torch.zeros(1, dtype=torch.int32, device=self.dev)
+
+    def _merge(self, ids, dists, k):
+        """local [nq, kk] (local ids, int32 view of uint32) -> global top-k over all ranks, on the device"""
+        import ctypes as C
+        from ._capi import check
+        nq = ids.shape[0]
+        gids = torch.where(ids == -1, ids, ids + self.lo)                   # -1 == 0xFFFFFFFF: unused slot of a short list
+        all_i = all_gather_tensor(gids)                                     # [W, nq, kk]
+        all_d = all_gather_tensor(dists)
+        oi = torch.empty((nq, k), dtype=torch.int32, device=self.dev)
+        od = torch.empty((nq, k), dtype=torch.float32, device=self.dev)
+        st = torch.cuda.current_stream(self.dev)
+        check(self.ix._lib.pann_merge_topk_dev(all_i.data_ptr(), all_d.data_ptr(), all_i.shape[0], nq, ids.shape[1], k, oi.data_ptr(),
+                                               od.data_ptr(), C.c_void_p(st.cuda_stream)))
+        return oi, od
+
+    def bruteforce(self, queries, k):
+        """exact ground truth over all shards (not a timed path: the per-shard brute force takes host arrays)"""
+        li, ld = self.ix.bruteforce_knn(queries, k)
+        return self._merge(torch.from_numpy(li.view(np.int32)).to(self.dev), torch.from_numpy(ld).to(self.dev), k)
 
     def search(self, d_queries, k, beam, cut=1.35):
         """d_queries: [nq, row bytes] uint8 device tensor (raw rows of the index dtype).  Returns (ids, dists) device tensors
@@ -147,14 +171,7 @@ class DeviceShardedIndex:
         st = torch.cuda.current_stream(self.dev)
         check(lib.pann_batch_search_dev(self.ix.handle, d_queries.data_ptr(), None, nq, d_queries.shape[1], self._starts.data_ptr(), 1,
                                         C.byref(qp), C.byref(out), C.c_void_p(st.cuda_stream)))
-        gids = torch.where(ids == -1, ids, ids + self.lo)                   # -1 == 0xFFFFFFFF: unused slot of a short list
-        all_i = all_gather_tensor(gids)                                     # [W, nq, k]
-        all_d = all_gather_tensor(dists)
-        oi = torch.empty((nq, k), dtype=torch.int32, device=self.dev)
-        od = torch.empty((nq, k), dtype=torch.float32, device=self.dev)
-        check(lib.pann_merge_topk_dev(all_i.data_ptr(), all_d.data_ptr(), all_i.shape[0], nq, k, k, oi.data_ptr(), od.data_ptr(),
-                                      C.c_void_p(st.cuda_stream)))
-        return oi, od
+        return self._merge(ids, dists, k)
 
     def close(self):
         self.ix.close()

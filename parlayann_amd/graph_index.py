@@ -86,10 +86,15 @@ class GraphIndex:
         return self._search(io.read_bin(queries, self.T), knn, beam_width, quant, visit_limit)
 
     def check_recall(self, queries_file, graph_file, neighbors, k):             # :259-305
-        gt_ids, gt_d = io.read_ibin(graph_file)
+        gt_ids, _ = io.read_ibin(graph_file)
         neighbors = np.asarray(neighbors)
         if neighbors.size and (neighbors[:, :k].max() >= len(self.points)):
             raise RuntimeError("neighbor reported by query out of range")
+        # resolve_eq_distances (:263,:275-283): the tie set comes from distances RECOMPUTED between the query file's points and
+        # this index's (full-precision) points, not from the distance column of the ground-truth file -- one rerank launch,
+        # resort off = the given order with exact distances
+        queries = io.read_bin(queries_file, self.T)
+        _, gt_d = self.index.rerank(np.ascontiguousarray(queries, dtype=self.T), gt_ids, None, gt_ids.shape[1], resort=False)
         rec = recall_at_k(neighbors, gt_ids, gt_d, k)
         print(f"Recall: {rec:.6g}")
         return rec

@@ -35,6 +35,10 @@ def test_uint8_euclidian_index_end_to_end(tmp_path, oracle, capsys):
     io.write_ibin(tmp_path / "gt", gt, gd)
     rec = Index.check_recall(str(tmp_path / "q.bin"), str(tmp_path / "gt"), ids, 10)
     assert "Recall: " in capsys.readouterr().out and abs(rec - oracle.recall(ids, gt, gd, 10)) < 1e-9
+    # the tie set is recomputed from the points (graph_index.cpp:275-283): a ground-truth file whose distance column is
+    # wrong (other tools store sqrt'd / rounded / differently signed distances) gives the same recall
+    io.write_ibin(tmp_path / "gt_bad", gt, np.zeros_like(gd))
+    assert Index.check_recall(str(tmp_path / "q.bin"), str(tmp_path / "gt_bad"), ids, 10) == rec
     with pytest.raises(Exception):
         wrapper.load_index("cosine", "uint8", "x", "y")
 
