@@ -108,9 +108,10 @@ def test_build_with_batches_above_2048_inserts(oracle):
 def test_real_valued_build_matches_oracle_quality(oracle):
     """DEEP-shaped (real-valued, unit-norm) f32: device and CPU sum floats in different orders
     (DESIGN.md "float order"), so graphs are not bit-identical; north_star asks for recall within
-    +-0.1 % of the CPU path.  Tolerances written here: recall@10 within 0.003 of the oracle-built graph
-    (same search, 1000 queries), average degree within 1 %, search on ONE graph: recall within 0.001."""
-    n, nq = 30000, 1000
+    +-0.1 % of the CPU path.  Tolerances written here: recall@10 within 0.001 (= north_star's 0.1 %) of the
+    oracle-built graph (same search, 4000 queries = 40 000 neighbour slots, so 0.001 is 40 slots and not
+    sampling noise), average degree within 1 %, search on ONE graph: recall within 0.001."""
+    n, nq = 30000, 4000
     X = datasets.deep_like(n, 96, seed=1234)
     Q = datasets.deep_like(nq, 96, seed=4321)
     Go, _ = oracle.vamana_build(X, 32, 64, 1.2, num_passes=1, seed=11)
@@ -120,7 +121,7 @@ def test_real_valued_build_matches_oracle_quality(oracle):
     gt, gd = oracle.bruteforce_knn(X, Q, 100)
     r_oo = oracle.recall(oracle.batch_search(X, Go, queries=Q, k=10, beam=48)["ids"], gt, gd, 10)
     r_do = oracle.recall(oracle.batch_search(X, Gd, queries=Q, k=10, beam=48)["ids"], gt, gd, 10)
-    assert abs(r_oo - r_do) <= 0.003, (r_oo, r_do)
+    assert abs(r_oo - r_do) <= 0.001, (r_oo, r_do)
     assert abs(Go[:, 0].mean() - Gd[:, 0].mean()) <= 0.01 * Go[:, 0].mean()
     same_rows = np.mean([set(Go[i, 1:1 + Go[i, 0]]) == set(Gd[i, 1:1 + Gd[i, 0]]) for i in range(0, n, 7)])
     assert same_rows > 0.9          # almost every adjacency list is the same set of neighbours
