@@ -695,10 +695,11 @@ int pann_bruteforce_knn(pann_index* idx, const void* queries, uint64_t nq, uint6
   uint32_t want = 1;
   {
     double best = -1.0;
-    const uint32_t smax = std::max<uint32_t>(8, (256 + ntiles - 1) / ntiles);
+    const double slots = (double)dense_gt_slots(idx->ix, k);       // 256 x the workgroups a CU holds (1 for the LDS-list kernels)
+    const uint32_t smax = std::max<uint32_t>(8, ((uint32_t)slots + ntiles - 1) / ntiles);
     for (uint32_t sp = 1; sp <= smax; sp++) {
       const double wgs = (double)ntiles * sp;
-      const double fill = wgs / (256.0 * std::ceil(wgs / 256.0)) - 0.02 * std::min<uint32_t>(sp, 8);
+      const double fill = wgs / (slots * std::ceil(wgs / slots)) - 0.02 * std::min<uint32_t>(sp, 8);
       if (fill > best + 1e-9) { best = fill; want = sp; }
     }
   }

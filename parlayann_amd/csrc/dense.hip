@@ -597,6 +597,251 @@ __global__ void __launch_bounds__(256) dense_topk_mfma_f16_kernel(DenseArgs A) {
   }
 }
 
+// ---- ground-truth variant (m in 17..128, two-byte floats, rows of at most 256 bytes, B = all points) ----
+// The kernel above keeps the per-row lists in LDS: at k = 100 that is 57 KB per workgroup (ONE workgroup per CU, every
+// barrier and LDS round trip exposed) and an insert is a read-shift-write chain through LDS.  Here
+//   * the lists live in REGISTERS: a wave owns 16 A rows, the list of a row is 128 keys = 2 x uint64 per lane (key p of the
+//     sorted list in lane p & 63 of register p >> 6); an insert is a wave-wide compare + shift by one lane (DPP wave_shr:1)
+//     + max -- about 25 VALU instructions and no memory;
+//   * a lane tests its 16 distances of a tile against FLOAT copies of its rows' m-th best (4 registers); only a tile with
+//     a survivor enters the insert loop, whose exact 64-bit compare decides ties;
+//   * the A fragments of the wave stay in registers for the whole launch (the A tile is fixed), only B goes through LDS,
+//     double-buffered: tile i+1 is written to the other buffer while tile i is multiplied and tile i+2 is in flight from
+//     HBM in registers -- one barrier per tile;
+//   * |b|^2 comes from a prepass over the points (row_norms_kernel) instead of being re-summed by each of the
+//     na/64 workgroups that stream the same rows.
+// LDS is 36 KB per workgroup, so 2-3 workgroups share a CU (register-bound).  Results are the same sets as the
+// kernel above: a row's list ends as the m smallest (distance, id) keys of its piece, whatever the insert order.
+constexpr int GT_BT_BYTES = DT_B * DT_BSTRIDE;
+
+template <bool BF>
+__device__ __forceinline__ float sumsq16(uint4 v) {
+  float ss = 0.f;
+  if constexpr (BF) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const float lo = bf16_lo(w[i]), hi = bf16_hi(w[i]); ss = fmaf(lo, lo, ss); ss = fmaf(hi, hi, ss); }
+  } else {
+    mf_half8 h; __builtin_memcpy(&h, &v, 16);
+#pragma unroll
+    for (int i = 0; i < 8; i++) { const float f = (float)h[i]; ss = fmaf(f, f, ss); }
+  }
+  return ss;
+}
+
+// |row|^2 of every point, summed like the staging code of the kernel above (16 lanes x 16 bytes, f32 fma chain per lane,
+// butterfly over the 16 lanes)
+template <bool BF>
+__global__ void __launch_bounds__(256) row_norms_kernel(const uint8_t* points, uint32_t pstride, uint64_t n, float* out) {
+  const uint64_t row = (uint64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int c = threadIdx.x & 15;
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (row < n) v = load16_guarded(points + row * pstride, c * 16, pstride);
+  const float ss = group_sum<16>(sumsq16<BF>(v));
+  if (row < n && c == 0) out[row] = ss;
+}
+
+// One insert step on the 128-key list of a row, held by the 16 lanes of a quarter in 8 registers (key p in register p >> 4,
+// lane p & 15 of the quarter): every key above x moves one place up (row_shr:1 inside a register, row_ror:1 carries lane 15
+// of register j-1 into lane 0 of register j), x lands in the gap, the largest key drops out.  The four quarters of the wave
+// run this together, each on its own row with its own x (KEY_INF: nothing to insert, the list is unchanged).
+template <int CTRL>
+__device__ __forceinline__ uint64_t gt_dpp64(uint64_t old, uint64_t v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)old, (int)(uint32_t)v, CTRL, 0xF, 0xF, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(old >> 32), (int)(uint32_t)(v >> 32), CTRL, 0xF, 0xF, false);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ void gt_quarter_insert(uint64_t (&R)[8], uint64_t x) {
+#pragma unroll
+  for (int j = 7; j >= 0; j--) {
+    uint64_t prev = 0ull;
+    if (j > 0) prev = gt_dpp64<0x121>(0ull, R[j - 1]);       // row_ror:1 -- lane 0 of the quarter <- lane 15 of register j-1
+    prev = gt_dpp64<0x111>(prev, R[j]);                       // row_shr:1 -- lanes 1..15 <- lane-1 of register j; lane 0 keeps the carry
+    const uint64_t in = prev > x ? prev : x;                  // the key below also moves: take it; else x lands here
+    R[j] = R[j] > x ? in : R[j];
+  }
+}
+
+template <int METRIC, bool BF>
+__global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, const float* __restrict__ bnorm) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  uint8_t* Bt0 = smem;                                                    // [2][64][DT_BSTRIDE]
+  float2* Bm = reinterpret_cast<float2*>(smem + 2 * GT_BT_BYTES);         // [2][64] (|b|^2, id bits)
+  float* An = reinterpret_cast<float*>(Bm + 2 * DT_B);                    // [64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4;
+  const uint64_t a0 = (uint64_t)blockIdx.x * DT_A;
+  const uint32_t na_tile = (uint32_t)min((uint64_t)DT_A, A.na - a0);
+  const uint64_t per = ((A.nb + A.nsplit - 1) / A.nsplit + DT_B - 1) / DT_B * DT_B;
+  const uint64_t bs = min(A.nb, (uint64_t)blockIdx.y * per), be = min(A.nb, (uint64_t)(blockIdx.y + 1) * per);
+  const uint32_t ntile = (uint32_t)((be - bs + DT_B - 1) / DT_B);
+  const uint32_t a_valid = A.a_ids ? A.pstride : A.dbytes;
+  auto a_load = [&](uint32_t r, uint32_t off) -> uint4 {
+    if (r >= na_tile) return make_uint4(0, 0, 0, 0);
+    const uint8_t* rp = A.a_ids ? A.points + (uint64_t)A.a_ids[a0 + r] * A.pstride : A.a_ext + (a0 + r) * A.a_stride;
+    if ((reinterpret_cast<uintptr_t>(rp) & 15) == 0) return load16_guarded(rp, off, a_valid);
+    uint8_t tmp[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) tmp[i] = (off + i < a_valid) ? rp[off + i] : (uint8_t)0;
+    uint4 v; __builtin_memcpy(&v, tmp, 16);
+    return v;
+  };
+  const int r0 = tid >> 4, c = tid & 15;
+  // |a|^2 of the 64 A rows (same summation as the staging code above)
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const float ss = group_sum<16>(sumsq16<BF>(a_load(r0 + 16 * k, c * 16)));
+    if (c == 0) An[r0 + 16 * k] = ss;
+  }
+  // A fragments of this wave: row wave*16 + (lane & 15), bytes ks*64 + q*16 .. +16 of it, for the 4 k-steps of a 256-byte row
+  uint4 af[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) af[ks] = a_load(wave * DT_AW + (lane & 15), ks * 64 + q * 16);
+  const uint32_t ksteps = (A.pstride + 63) / 64;
+
+  // lists: R[r] = row 4q + r of this wave, right-aligned in 128 places (the leading 128 - m hold key 0, which nothing
+  // displaces), so the m-th best of a row is always place 127 = register 7, lane 15 of the quarter
+  uint64_t R[4][8];
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) R[r][j] = (uint32_t)(j * 16 + (lane & 15)) < 128u - A.m ? 0ull : KEY_INF;
+  __syncthreads();
+  float an[4], tauf[4];
+  bool rowok[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const uint32_t ar = wave * DT_AW + q * 4 + r;
+    an[r] = An[ar];
+    rowok[r] = ar < na_tile;
+    tauf[r] = rowok[r] ? __builtin_inff() : -__builtin_inff();             // a padding row accepts nothing
+  }
+
+  uint4 pre[4];
+  float pn = 0.f;
+  auto load_pre = [&](uint64_t bt) {
+    const uint32_t nrows = (uint32_t)min((uint64_t)DT_B, be - bt);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int r = r0 + 16 * k;
+      pre[k] = make_uint4(0, 0, 0, 0);
+      if (r < (int)nrows) pre[k] = load16_guarded(A.points + (bt + r) * A.pstride, c * 16, A.pstride);
+    }
+    if (tid < DT_B) pn = (METRIC == PANN_L2 && tid < (int)nrows) ? bnorm[bt + tid] : 0.f;
+  };
+  auto store_pre = [&](int buf, uint64_t bt) {
+    const uint32_t nrows = (uint32_t)min((uint64_t)DT_B, be - bt);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      *reinterpret_cast<uint4*>(Bt0 + buf * GT_BT_BYTES + (size_t)(r0 + 16 * k) * DT_BSTRIDE + c * 16) = pre[k];
+    if (tid < DT_B) Bm[buf * DT_B + tid] = make_float2(pn, __uint_as_float(tid < (int)nrows ? (uint32_t)(bt + tid) : SENTINEL));
+  };
+  if (ntile > 0) { load_pre(bs); store_pre(0, bs); }
+  if (ntile > 1) load_pre(bs + DT_B);
+  __syncthreads();
+
+  for (uint32_t i = 0; i < ntile; i++) {
+    const uint64_t bt = bs + (uint64_t)i * DT_B;
+    const int buf = (int)(i & 1);
+    if (i + 1 < ntile) store_pre(buf ^ 1, bt + DT_B);          // tile i+1 (requested one iteration ago) -> the other buffer
+    if (i + 2 < ntile) load_pre(bt + 2 * DT_B);                // tile i+2 -> registers, in flight during this tile's math
+    mf_float4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[t] = mf_float4{0.f, 0.f, 0.f, 0.f};
+    const uint8_t* Bt = Bt0 + buf * GT_BT_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      if (ks < (int)ksteps) {
+        const uint32_t koff = ks * 64 + q * 16;
+        if constexpr (BF) {
+          mf_bf8 a8; __builtin_memcpy(&a8, &af[ks], 16);
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            const mf_bf8 b8 = *reinterpret_cast<const mf_bf8*>(Bt + (size_t)(t * 16 + (lane & 15)) * DT_BSTRIDE + koff);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, acc[t], 0, 0, 0);
+          }
+        } else {
+          mf_half8 a8; __builtin_memcpy(&a8, &af[ks], 16);
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            const mf_half8 b8 = *reinterpret_cast<const mf_half8*>(Bt + (size_t)(t * 16 + (lane & 15)) * DT_BSTRIDE + koff);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, b8, acc[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // ---- epilogue: acc[t][r] = a(row wave*16 + 4q + r) . b(column t*16 + (lane & 15)) ----
+    float bn[4]; uint32_t bid[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) { const float2 m2 = Bm[buf * DT_B + t * 16 + (lane & 15)]; bn[t] = m2.x; bid[t] = __float_as_uint(m2.y); }
+    float dist[4][4];
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        if constexpr (METRIC == PANN_L2) dist[r][t] = (an[r] + bn[t]) - 2.0f * acc[t][r];
+        else dist[r][t] = -acc[t][r];
+        any = any || (dist[r][t] <= tauf[r]);
+      }
+    }
+    if (__any(any)) {
+      // rows 4c + r (c = 0..3) of this wave, one r at a time: every lane offers its first still-pending column
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        uint32_t pend = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) pend |= (dist[r][t] <= tauf[r] && bid[t] != SENTINEL) ? (1u << t) : 0u;
+        uint64_t mask = __ballot(pend != 0);
+        while (mask) {
+          // every lane offers its first pending column; each quarter takes the offer of its first offering lane
+          const int t0 = __ffs(pend) - 1;
+          const float dsel = t0 == 0 ? dist[r][0] : t0 == 1 ? dist[r][1] : t0 == 2 ? dist[r][2] : dist[r][3];
+          const uint32_t isel = t0 == 0 ? bid[0] : t0 == 1 ? bid[1] : t0 == 2 ? bid[2] : bid[3];
+          const uint32_t osel = f2ord(dsel);
+          uint32_t xh = 0xFFFFFFFFu, xl = 0xFFFFFFFFu;
+          int mine = -1;
+#pragma unroll
+          for (int C = 0; C < 4; C++) {
+            const uint32_t field = (uint32_t)(mask >> (16 * C)) & 0xFFFFu;
+            const int L = 16 * C + (field ? __builtin_ctz(field) : 0);
+            const uint32_t h = field ? __builtin_amdgcn_readlane(osel, L) : 0xFFFFFFFFu;
+            const uint32_t l = field ? __builtin_amdgcn_readlane(isel, L) : 0xFFFFFFFFu;
+            if (q == C) { xh = h; xl = l; mine = field ? L : -1; }
+          }
+          if (lane == mine) pend &= pend - 1;
+          gt_quarter_insert(R[r], ((uint64_t)xh << 32) | xl);
+          // the row's m-th best may have tightened: refresh the float threshold, drop what no longer passes
+          uint32_t th = 0;
+#pragma unroll
+          for (int C = 0; C < 4; C++) {
+            const uint32_t h = __builtin_amdgcn_readlane((uint32_t)(R[r][7] >> 32), 16 * C + 15);
+            if (q == C) th = h;
+          }
+          tauf[r] = !rowok[r] ? -__builtin_inff() : (th == 0xFFFFFFFFu ? __builtin_inff() : ord2f(th));
+#pragma unroll
+          for (int t = 0; t < 4; t++) pend &= (dist[r][t] <= tauf[r]) ? ~0u : ~(1u << t);
+          mask = __ballot(pend != 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- this piece's lists -> partial[row][piece][0..m): place p of a list is entry p - (128 - m) ----
+  const uint32_t lead = 128u - A.m;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const uint32_t ar = wave * DT_AW + q * 4 + r;
+    if (ar < na_tile) {
+      uint64_t* out = A.partial + ((a0 + ar) * A.nsplit + blockIdx.y) * A.m;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const uint32_t p = (uint32_t)(j * 16 + (lane & 15));
+        if (p >= lead) out[p - lead] = R[r][j];
+      }
+    }
+  }
+}
+
 // merge the nsplit partial lists of each A row (one wave per row) and write ids / dists
 __global__ void __launch_bounds__(64) dense_merge_kernel(const uint64_t* partial, uint64_t na, uint32_t nsplit,
                                                          uint32_t m, uint32_t mcap, uint32_t* out_ids, float* out_dists) {
@@ -631,6 +876,25 @@ __global__ void __launch_bounds__(64) dense_merge_kernel(const uint64_t* partial
 
 // ---------------------------------------------------------------------------------------------
 
+constexpr size_t GT_LDS_BYTES = 2 * (size_t)GT_BT_BYTES + 2 * DT_B * sizeof(float2) + DT_A * sizeof(float);
+
+bool dense_gt_eligible(const DeviceIndex& ix, uint32_t m, bool b_ids, bool segmented, int exclude_same) {
+  static const bool off = getenv("PANN_GT_OLD") != nullptr;      // diagnostic A/B switch
+  return !off && m > 16 && m <= 128 && !ix.exact && (ix.dtype == PANN_F16 || ix.dtype == PANN_BF16) && ix.pstride <= 256 &&
+         !b_ids && !segmented && !exclude_same;
+}
+
+// workgroups of the ground-truth launch that are resident at once (for the caller's choice of nsplit)
+uint32_t dense_gt_slots(const DeviceIndex& ix, uint32_t m) {
+  if (!dense_gt_eligible(ix, m, false, false, 0)) return 256;
+  int nb = 0;
+  const void* f = ix.dtype == PANN_BF16
+      ? (ix.metric == PANN_L2 ? (const void*)dense_gt_mfma_kernel<PANN_L2, true> : (const void*)dense_gt_mfma_kernel<PANN_MIPS, true>)
+      : (ix.metric == PANN_L2 ? (const void*)dense_gt_mfma_kernel<PANN_L2, false> : (const void*)dense_gt_mfma_kernel<PANN_MIPS, false>);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, 256, GT_LDS_BYTES) != hipSuccess || nb < 1) nb = 1;
+  return 256u * (uint32_t)nb;
+}
+
 static size_t dense_lds_bytes(uint32_t mcap) {
   return (size_t)DT_A * DT_SEG + (size_t)DT_B * DT_RB * DT_BSTRIDE + (DT_A + DT_B * DT_RB) * 4 + (size_t)DT_A * mcap * 8;
 }
@@ -652,6 +916,28 @@ int dense_topk_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, const u
   A.exclude_same_id = exclude_same; A.exact = ix.exact; A.partial = (uint64_t*)ws.buf; A.tile_seg = d_tile_seg; A.tile_a0 = d_tile_a0;
   const size_t lds = dense_lds_bytes(mcap);
   const dim3 grid(ntiles, nsplit);
+  if (dense_gt_eligible(ix, m, d_b_ids != nullptr, d_a_off || d_b_off || d_tile_seg || d_tile_a0, exclude_same)) {
+    // register-list ground-truth kernel; |b|^2 of every point first (after the partial lists in the workspace)
+    const size_t poff = (pbytes + 255) / 256 * 256;
+    if (int rc = ws.ensure(poff + (size_t)nb * 4 + 256)) return rc;
+    A.partial = (uint64_t*)ws.buf;
+    float* d_norm = reinterpret_cast<float*>(static_cast<uint8_t*>(ws.buf) + poff);
+    const bool bf = ix.dtype == PANN_BF16;
+    if (ix.metric == PANN_L2) {
+      const dim3 ng((uint32_t)((nb + 15) / 16));
+      if (bf) hipLaunchKernelGGL(row_norms_kernel<true>, ng, dim3(256), 0, st, ix.points, ix.pstride, nb, d_norm);
+      else hipLaunchKernelGGL(row_norms_kernel<false>, ng, dim3(256), 0, st, ix.points, ix.pstride, nb, d_norm);
+    }
+#define CALL_GT(MT, BF) hipLaunchKernelGGL((dense_gt_mfma_kernel<MT, BF>), grid, dim3(256), GT_LDS_BYTES, st, A, (const float*)d_norm)
+    if (bf) { if (ix.metric == PANN_L2) CALL_GT(PANN_L2, true); else CALL_GT(PANN_MIPS, true); }
+    else { if (ix.metric == PANN_L2) CALL_GT(PANN_L2, false); else CALL_GT(PANN_MIPS, false); }
+#undef CALL_GT
+    PANN_HIP(hipGetLastError());
+    hipLaunchKernelGGL(dense_merge_kernel, dim3((uint32_t)na), dim3(64), (size_t)mcap * 8, st,
+                       (const uint64_t*)ws.buf, na, nsplit, m, mcap, d_out_ids, d_out_dists);
+    PANN_HIP(hipGetLastError());
+    return PANN_OK;
+  }
 #define CALL_DENSE(DT, MT)                                                                              \
   do {                                                                                                   \
     auto kern = dense_topk_kernel<DT, MT>;                                                               \

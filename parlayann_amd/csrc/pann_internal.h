@@ -101,6 +101,8 @@ int rerank_dev(const DeviceIndex& ix, hipStream_t st, const uint8_t* d_q, uint64
                float* d_out_dists);
 
 // leaf_knn.hip: lane-owns-row all-pairs top-m for one-byte element types (HCNNG leaves)
+bool dense_gt_eligible(const DeviceIndex& ix, uint32_t m, bool b_ids, bool segmented, int exclude_same);
+uint32_t dense_gt_slots(const DeviceIndex& ix, uint32_t m);
 bool leaf_knn_rows_eligible(const DeviceIndex& ix, uint32_t m);
 int leaf_knn_rows_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, const uint32_t* d_ids, const uint64_t* d_off,
                       const uint64_t* h_off, uint64_t nseg, uint32_t m, int exclude_same, uint32_t* d_out_ids, float* d_out_dists);

@@ -45,6 +45,28 @@ def test_bruteforce_knn(oracle, dtype, metric, d, k):
     ix.close()
 
 
+@pytest.mark.parametrize("metric,d,k,n,nq,nsplit", [
+    ("l2", 128, 100, 20000, 130, None), ("l2", 128, 17, 5000, 64, None), ("l2", 128, 64, 5000, 65, 3),
+    ("l2", 128, 65, 5000, 1, 2), ("l2", 128, 128, 9000, 200, 1), ("mips", 128, 100, 9000, 33, 4),
+    ("l2", 64, 100, 6000, 70, None), ("l2", 100, 50, 6000, 70, None), ("l2", 32, 100, 700, 20, 5),
+    ("l2", 128, 100, 50, 10, None), ("l2", 128, 100, 64, 64, 1), ("mips", 96, 30, 129, 3, 2),
+])
+def test_bruteforce_register_list_kernel(oracle, monkeypatch, metric, d, k, n, nq, nsplit):
+    """two-byte floats, rows <= 256 bytes, k in 17..128: dense_gt_mfma_kernel (lists in registers, B double-buffered);
+    partial tiles, fewer points than k, one query, every piece count"""
+    if nsplit:
+        monkeypatch.setenv("PANN_GT_NSPLIT", str(nsplit))
+    X = _mk(n, d, np.float16)
+    Q = _mk(nq, d, np.float16, seed=4321)
+    X[n // 2] = X[n // 3]                      # equal distances: the id decides (check_nn_recall-style ties)
+    ix = DeviceIndex(X, max_degree=8, metric=metric)
+    gi, gd = ix.bruteforce_knn(Q, k)
+    oi, od = oracle.bruteforce_knn(X, Q, k, metric=metric)
+    np.testing.assert_array_equal(oi, gi)
+    np.testing.assert_array_equal(od, gd)
+    ix.close()
+
+
 @pytest.mark.parametrize("dtype,metric,d", [(np.uint8, "l2", 128), (np.int8, "l2", 100), (np.float32, "mips", 200),
                                             (np.float16, "mips", 128), (np.uint8, "mips", 32)])
 def test_plain_distances(oracle, dtype, metric, d):
