@@ -613,6 +613,7 @@ __global__ void __launch_bounds__(256) dense_topk_mfma_f16_kernel(DenseArgs A) {
 // LDS is 36 KB per workgroup, so 2-3 workgroups share a CU (register-bound).  Results are the same sets as the
 // kernel above: a row's list ends as the m smallest (distance, id) keys of its piece, whatever the insert order.
 constexpr int GT_BT_BYTES = DT_B * DT_BSTRIDE;
+constexpr uint32_t GT_TAU_PERIOD = 8;      // tiles between two looks at what the other pieces of a row have published
 
 template <bool BF>
 __device__ __forceinline__ float sumsq16(uint4 v) {
@@ -662,8 +663,21 @@ __device__ __forceinline__ void gt_quarter_insert(uint64_t (&R)[8], uint64_t x) 
   }
 }
 
+#ifdef PANN_GT_COUNTERS
+// diagnostic build only (make alt ALTFLAGS=-DPANN_GT_COUNTERS): [0] tiles x waves, [1] tiles entering the insert path,
+// [2] insert rounds, [3] offers that really entered a list
+__device__ unsigned long long gt_counters[8];
+#define GT_COUNT(i, v) do { if (lane == 0) atomicAdd(&gt_counters[i], (unsigned long long)(v)); } while (0)
+#else
+#define GT_COUNT(i, v) do { } while (0)
+#endif
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains the vector memory counter, which would wait
+// for the tile requested two iterations ahead at every tile (measured: 2.6 us per tile, the loaded HBM latency)
+__device__ __forceinline__ void gt_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int METRIC, bool BF>
-__global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, const float* __restrict__ bnorm) {
+__global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, const float* __restrict__ bnorm, uint32_t* gtau) {
   extern __shared__ __align__(16) uint8_t smem[];
   uint8_t* Bt0 = smem;                                                    // [2][64][DT_BSTRIDE]
   float2* Bm = reinterpret_cast<float2*>(smem + 2 * GT_BT_BYTES);         // [2][64] (|b|^2, id bits)
@@ -696,7 +710,6 @@ __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, cons
   uint4 af[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ks++) af[ks] = a_load(wave * DT_AW + (lane & 15), ks * 64 + q * 16);
-  const uint32_t ksteps = (A.pstride + 63) / 64;
 
   // lists: R[r] = row 4q + r of this wave, right-aligned in 128 places (the leading 128 - m hold key 0, which nothing
   // displaces), so the m-th best of a row is always place 127 = register 7, lane 15 of the quarter
@@ -716,41 +729,83 @@ __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, cons
     tauf[r] = rowok[r] ? __builtin_inff() : -__builtin_inff();             // a padding row accepts nothing
   }
 
-  uint4 pre[4];
+  const uint32_t pplace = 128u - A.m + (A.m + A.nsplit - 1) / A.nsplit - 1;      // list place of the ceil(m/nsplit)-th best
+  const uint32_t tau_period = GT_TAU_PERIOD * ((A.nsplit + 7) / 8);
+  uint32_t tau_wait = tau_period;
+  uint32_t pub[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};       // last value published per row (lane 0 of the quarter)
+
+  uint4 pre0, pre1, pre2, pre3;
   float pn = 0.f;
-  auto load_pre = [&](uint64_t bt) {
-    const uint32_t nrows = (uint32_t)min((uint64_t)DT_B, be - bt);
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int r = r0 + 16 * k;
-      pre[k] = make_uint4(0, 0, 0, 0);
-      if (r < (int)nrows) pre[k] = load16_guarded(A.points + (bt + r) * A.pstride, c * 16, A.pstride);
-    }
-    if (tid < DT_B) pn = (METRIC == PANN_L2 && tid < (int)nrows) ? bnorm[bt + tid] : 0.f;
+  // Branch-free, mask-free staging: rows are 16-byte aligned, a multiple of 16 bytes long and zero padded
+  // (pann_index_create), so every lane reads a clamped row unconditionally; a row index beyond the piece re-reads the
+  // piece's last row and is labelled SENTINEL (never offered to a list).  Lanes whose 16-byte column lies beyond the row
+  // length do not write at all: their LDS columns are zeroed once, below.  (With the guarded loader's byte-wise tail
+  // path in the loop the compiler drained the vector memory counter before the first MFMA of every tile.)
+  const uint32_t nchunk = A.pstride >> 4;
+  const bool cvalid = (uint32_t)c < nchunk;
+  const uint8_t* cbase = A.points + min((uint32_t)c, nchunk - 1u) * 16u;
+  const uint32_t last_row = (uint32_t)(be - 1);                    // be > bs wherever a load is issued; ids are 32-bit
+  // (four named registers, not an array: as an array the compiler kept the tile in scratch memory)
+  auto brow = [&](uint64_t bt, int k) -> const uint4* {
+    return reinterpret_cast<const uint4*>(cbase + (uint64_t)min((uint32_t)bt + (uint32_t)(r0 + 16 * k), last_row) * A.pstride);
+  };
+  auto load_pre = [&](uint64_t bt) {          // requests only: nothing here may depend on the loaded values
+    pre0 = *brow(bt, 0); pre1 = *brow(bt, 1); pre2 = *brow(bt, 2); pre3 = *brow(bt, 3);
+    if (METRIC == PANN_L2) pn = bnorm[min((uint32_t)bt + (uint32_t)lane, last_row)];       // every wave: no branch around a load
   };
   auto store_pre = [&](int buf, uint64_t bt) {
-    const uint32_t nrows = (uint32_t)min((uint64_t)DT_B, be - bt);
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      *reinterpret_cast<uint4*>(Bt0 + buf * GT_BT_BYTES + (size_t)(r0 + 16 * k) * DT_BSTRIDE + c * 16) = pre[k];
-    if (tid < DT_B) Bm[buf * DT_B + tid] = make_float2(pn, __uint_as_float(tid < (int)nrows ? (uint32_t)(bt + tid) : SENTINEL));
+    if (cvalid) {
+      uint8_t* dst = Bt0 + buf * GT_BT_BYTES + (size_t)r0 * DT_BSTRIDE + c * 16;
+      *reinterpret_cast<uint4*>(dst) = pre0;
+      *reinterpret_cast<uint4*>(dst + 16 * DT_BSTRIDE) = pre1;
+      *reinterpret_cast<uint4*>(dst + 32 * DT_BSTRIDE) = pre2;
+      *reinterpret_cast<uint4*>(dst + 48 * DT_BSTRIDE) = pre3;
+    }
+    if (tid < DT_B)
+      Bm[buf * DT_B + tid] = make_float2(pn, __uint_as_float(bt + tid < be ? (uint32_t)(bt + tid) : SENTINEL));
   };
-  if (ntile > 0) { load_pre(bs); store_pre(0, bs); }
-  if (ntile > 1) load_pre(bs + DT_B);
-  __syncthreads();
+  if (!cvalid) {
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      *reinterpret_cast<uint4*>(Bt0 + (k >> 2) * GT_BT_BYTES + (size_t)(r0 + 16 * (k & 3)) * DT_BSTRIDE + c * 16) = make_uint4(0, 0, 0, 0);
+  }
+  if (ntile > 0) {           // (an empty piece issues no loads: last_row is meaningless there)
+    load_pre(bs); store_pre(0, bs);
+    load_pre(bs + DT_B);
+  }
+  gt_lds_barrier();
 
   for (uint32_t i = 0; i < ntile; i++) {
     const uint64_t bt = bs + (uint64_t)i * DT_B;
     const int buf = (int)(i & 1);
-    if (i + 1 < ntile) store_pre(buf ^ 1, bt + DT_B);          // tile i+1 (requested one iteration ago) -> the other buffer
-    if (i + 2 < ntile) load_pre(bt + 2 * DT_B);                // tile i+2 -> registers, in flight during this tile's math
+    if (--tau_wait == 0) {
+      // Every piece of a row publishes its ceil(m / nsplit)-th best.  The largest of those bounds the final m-th best from
+      // above (the pieces together hold at least m keys at or below it), so it is a valid threshold for every piece -- and
+      // much tighter than a piece's own m-th best, which has seen only 1/nsplit of the points.  A stale or missing value
+      // only lets more candidates through.
+      tau_wait = tau_period;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint32_t* gp = gtau + (a0 + min((uint32_t)(wave * DT_AW + q * 4 + r), na_tile - 1u)) * A.nsplit;
+        uint32_t g = 0;
+        for (uint32_t cpiece = 0; cpiece < A.nsplit; cpiece++)
+          g = max(g, __hip_atomic_load(gp + cpiece, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const float gf = g == 0xFFFFFFFFu ? __builtin_inff() : ord2f(g);
+        tauf[r] = rowok[r] ? fminf(tauf[r], gf) : tauf[r];
+      }
+    }
+    // No branches around these two: beyond the last tile they re-stage the piece's last row (clamped loads, SENTINEL labels)
+    // into the buffer nobody reads again -- with conditional staging the compiler waited for the requests just made
+    // before the first MFMA.
+    store_pre(buf ^ 1, bt + DT_B);                             // tile i+1 (requested one iteration ago) -> the other buffer
+    load_pre(bt + 2 * DT_B);                                   // tile i+2 -> registers, in flight during this tile's math
     mf_float4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) acc[t] = mf_float4{0.f, 0.f, 0.f, 0.f};
     const uint8_t* Bt = Bt0 + buf * GT_BT_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
-      if (ks < (int)ksteps) {
+    for (int ks = 0; ks < 4; ks++) {      // always the 4 k-steps of a 256-byte row: bytes beyond the row are zero in both tiles
+      {
         const uint32_t koff = ks * 64 + q * 16;
         if constexpr (BF) {
           mf_bf8 a8; __builtin_memcpy(&a8, &af[ks], 16);
@@ -784,7 +839,9 @@ __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, cons
         any = any || (dist[r][t] <= tauf[r]);
       }
     }
+    GT_COUNT(0, 1);
     if (__any(any)) {
+      GT_COUNT(1, 1);
       // rows 4c + r (c = 0..3) of this wave, one r at a time: every lane offers its first still-pending column
 #pragma unroll
       for (int r = 0; r < 4; r++) {
@@ -792,6 +849,7 @@ __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, cons
 #pragma unroll
         for (int t = 0; t < 4; t++) pend |= (dist[r][t] <= tauf[r] && bid[t] != SENTINEL) ? (1u << t) : 0u;
         uint64_t mask = __ballot(pend != 0);
+        bool touched = false;
         while (mask) {
           // every lane offers its first pending column; each quarter takes the offer of its first offering lane
           const int t0 = __ffs(pend) - 1;
@@ -809,6 +867,10 @@ __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, cons
             if (q == C) { xh = h; xl = l; mine = field ? L : -1; }
           }
           if (lane == mine) pend &= pend - 1;
+#ifdef PANN_GT_COUNTERS
+          GT_COUNT(2, 1);
+          GT_COUNT(3, __popcll(__ballot((lane & 15) == 15 && ((uint64_t)xh << 32 | xl) < R[r][7])));
+#endif
           gt_quarter_insert(R[r], ((uint64_t)xh << 32) | xl);
           // the row's m-th best may have tightened: refresh the float threshold, drop what no longer passes
           uint32_t th = 0;
@@ -817,14 +879,32 @@ __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, cons
             const uint32_t h = __builtin_amdgcn_readlane((uint32_t)(R[r][7] >> 32), 16 * C + 15);
             if (q == C) th = h;
           }
-          tauf[r] = !rowok[r] ? -__builtin_inff() : (th == 0xFFFFFFFFu ? __builtin_inff() : ord2f(th));
+          const float nt = th == 0xFFFFFFFFu ? __builtin_inff() : ord2f(th);
+          tauf[r] = !rowok[r] ? -__builtin_inff() : fminf(tauf[r], nt);
 #pragma unroll
           for (int t = 0; t < 4; t++) pend &= (dist[r][t] <= tauf[r]) ? ~0u : ~(1u << t);
           mask = __ballot(pend != 0);
+          touched = true;
+        }
+        if (touched) {
+          // this piece's share-th best (place pplace of the list): publish it when it improved
+          uint32_t ph = (uint32_t)(R[r][0] >> 32);
+#pragma unroll
+          for (int j = 1; j < 8; j++) ph = (pplace >> 4) == (uint32_t)j ? (uint32_t)(R[r][j] >> 32) : ph;
+          uint32_t pv = 0;
+#pragma unroll
+          for (int C = 0; C < 4; C++) {
+            const uint32_t h = __builtin_amdgcn_readlane(ph, 16 * C + (int)(pplace & 15));
+            if (q == C) pv = h;
+          }
+          if ((lane & 15) == 0 && rowok[r] && pv < pub[r]) {
+            pub[r] = pv;
+            __hip_atomic_store(gtau + (a0 + wave * DT_AW + q * 4 + r) * A.nsplit + blockIdx.y, pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
       }
     }
-    __syncthreads();
+    gt_lds_barrier();
   }
   // ---- this piece's lists -> partial[row][piece][0..m): place p of a list is entry p - (128 - m) ----
   const uint32_t lead = 128u - A.m;
@@ -919,16 +999,19 @@ int dense_topk_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, const u
   if (dense_gt_eligible(ix, m, d_b_ids != nullptr, d_a_off || d_b_off || d_tile_seg || d_tile_a0, exclude_same)) {
     // register-list ground-truth kernel; |b|^2 of every point first (after the partial lists in the workspace)
     const size_t poff = (pbytes + 255) / 256 * 256;
-    if (int rc = ws.ensure(poff + (size_t)nb * 4 + 256)) return rc;
+    const size_t noff = poff + ((size_t)nb * 4 + 255) / 256 * 256;
+    if (int rc = ws.ensure(noff + (size_t)na * nsplit * 4 + 256)) return rc;
     A.partial = (uint64_t*)ws.buf;
     float* d_norm = reinterpret_cast<float*>(static_cast<uint8_t*>(ws.buf) + poff);
+    uint32_t* d_gtau = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(ws.buf) + noff);      // [A row][piece]: the piece's ceil(m/nsplit)-th best so far
+    PANN_HIP(hipMemsetAsync(d_gtau, 0xFF, (size_t)na * nsplit * 4, st));
     const bool bf = ix.dtype == PANN_BF16;
     if (ix.metric == PANN_L2) {
       const dim3 ng((uint32_t)((nb + 15) / 16));
       if (bf) hipLaunchKernelGGL(row_norms_kernel<true>, ng, dim3(256), 0, st, ix.points, ix.pstride, nb, d_norm);
       else hipLaunchKernelGGL(row_norms_kernel<false>, ng, dim3(256), 0, st, ix.points, ix.pstride, nb, d_norm);
     }
-#define CALL_GT(MT, BF) hipLaunchKernelGGL((dense_gt_mfma_kernel<MT, BF>), grid, dim3(256), GT_LDS_BYTES, st, A, (const float*)d_norm)
+#define CALL_GT(MT, BF) hipLaunchKernelGGL((dense_gt_mfma_kernel<MT, BF>), grid, dim3(256), GT_LDS_BYTES, st, A, (const float*)d_norm, d_gtau)
     if (bf) { if (ix.metric == PANN_L2) CALL_GT(PANN_L2, true); else CALL_GT(PANN_MIPS, true); }
     else { if (ix.metric == PANN_L2) CALL_GT(PANN_L2, false); else CALL_GT(PANN_MIPS, false); }
 #undef CALL_GT
@@ -1111,3 +1194,12 @@ int rerank_dev(const DeviceIndex& ix, hipStream_t st, const uint8_t* d_q, uint64
 }
 
 }  // namespace pann
+
+#ifdef PANN_GT_COUNTERS
+extern "C" int pann_debug_gt_counters(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pann::gt_counters), 64) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(pann::gt_counters), z, 64) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
+

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""insert-path counters of the ground-truth kernel (diagnostic build: make -C parlayann_amd/csrc alt ALTFLAGS=-DPANN_GT_COUNTERS;
+run with PANN_LIBRARY=parlayann_amd/lib/libpann_alt.so).  usage: gt_counters.py [n] [nq] [k]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from parlayann_amd import DeviceIndex, datasets, _capi  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+nq = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000
+k = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+X = datasets.sift1m_like(n, 128, seed=1234, dtype=np.float16)
+Q = datasets.sift1m_like(nq, 128, seed=4321, dtype=np.float16)
+ix = DeviceIndex(X, max_degree=8)
+lib = C.CDLL(_capi.LIB_PATH)
+out = (C.c_ulonglong * 8)()
+lib.pann_debug_gt_counters(out, 1)
+ix.bruteforce_knn(Q, k)
+lib.pann_debug_gt_counters(out, 1)
+c = list(out)
+print(f"nsplit={os.environ.get('PANN_GT_NSPLIT', 'auto')}: wave-tiles {c[0]}, entering the insert path {c[1]} ({c[1] / max(c[0], 1):.3f}), "
+      f"rounds {c[2]} ({c[2] / max(c[0], 1):.3f}/wave-tile), real inserts {c[3]} ({c[3] / nq:.0f}/query)")
