@@ -676,6 +676,124 @@ __device__ unsigned long long gt_counters[8];
 // for the tile requested two iterations ahead at every tile (measured: 2.6 us per tile, the loaded HBM latency)
 __device__ __forceinline__ void gt_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// selection state of a wave in the ground-truth kernels: lists, float thresholds, what was published
+struct GtSel {
+  uint64_t R[4][8];      // R[r] = row 4q + r, right-aligned in 128 places (the leading 128 - m hold key 0, which nothing displaces):
+                         // the m-th best of a row is always place 127 = register 7, lane 15 of the quarter
+  float tauf[4];         // float copy of the row's threshold (min of its own m-th best and the bound shared by the pieces)
+  bool rowok[4];
+  uint32_t pub[4];       // last value published per row (lane 0 of the quarter)
+};
+__device__ __forceinline__ void gt_sel_init(GtSel& S, uint32_t m, uint32_t row0, uint32_t na_tile, int lane) {
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) S.R[r][j] = (uint32_t)(j * 16 + (lane & 15)) < 128u - m ? 0ull : KEY_INF;
+    S.rowok[r] = row0 + r < na_tile;
+    S.tauf[r] = S.rowok[r] ? __builtin_inff() : -__builtin_inff();        // a padding row accepts nothing
+    S.pub[r] = 0xFFFFFFFFu;
+  }
+}
+// Every piece of a row publishes its ceil(m / nsplit)-th best.  The largest of those bounds the final m-th best from above
+// (the pieces together hold at least m keys at or below it), so it is a valid threshold for every piece -- and much tighter
+// than a piece's own m-th best, which has seen only 1/nsplit of the points.  A stale or missing value only lets more
+// candidates through.
+__device__ __forceinline__ void gt_sel_refresh(GtSel& S, const uint32_t* gtau_rows, uint32_t row0, uint32_t na_tile, uint32_t nsplit) {
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const uint32_t* gp = gtau_rows + (size_t)min(row0 + r, na_tile - 1u) * nsplit;
+    uint32_t g = 0;
+    for (uint32_t cpiece = 0; cpiece < nsplit; cpiece++)
+      g = max(g, __hip_atomic_load(gp + cpiece, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const float gf = g == 0xFFFFFFFFu ? __builtin_inff() : ord2f(g);
+    S.tauf[r] = S.rowok[r] ? fminf(S.tauf[r], gf) : S.tauf[r];
+  }
+}
+// dist[r][t]: distance of row 4q + r to the column this lane holds in column block t (id bid[t], SENTINEL: no column).
+// Rows one r at a time; every lane offers its first still-pending column, each quarter takes the offer of its first lane.
+__device__ __forceinline__ void gt_select(GtSel& S, const float (&dist)[4][4], const uint32_t (&bid)[4], uint32_t pplace,
+                                          uint32_t* gtau_mine /* [row 4q of this wave][this piece] */, uint32_t nsplit, int lane) {
+  const int q = lane >> 4;
+  bool any = false;
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+#pragma unroll
+    for (int t = 0; t < 4; t++) any = any || (dist[r][t] <= S.tauf[r]);
+  if (!__any(any)) return;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    uint32_t pend = 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++) pend |= (dist[r][t] <= S.tauf[r] && bid[t] != SENTINEL) ? (1u << t) : 0u;
+    uint64_t mask = __ballot(pend != 0);
+    bool touched = false;
+    while (mask) {
+      const int t0 = __ffs(pend) - 1;
+      const float dsel = t0 == 0 ? dist[r][0] : t0 == 1 ? dist[r][1] : t0 == 2 ? dist[r][2] : dist[r][3];
+      const uint32_t isel = t0 == 0 ? bid[0] : t0 == 1 ? bid[1] : t0 == 2 ? bid[2] : bid[3];
+      const uint32_t osel = f2ord(dsel);
+      uint32_t xh = 0xFFFFFFFFu, xl = 0xFFFFFFFFu;
+      int mine = -1;
+#pragma unroll
+      for (int C = 0; C < 4; C++) {
+        const uint32_t field = (uint32_t)(mask >> (16 * C)) & 0xFFFFu;
+        const int L = 16 * C + (field ? __builtin_ctz(field) : 0);
+        const uint32_t h = field ? __builtin_amdgcn_readlane(osel, L) : 0xFFFFFFFFu;
+        const uint32_t l = field ? __builtin_amdgcn_readlane(isel, L) : 0xFFFFFFFFu;
+        if (q == C) { xh = h; xl = l; mine = field ? L : -1; }
+      }
+      if (lane == mine) pend &= pend - 1;
+      GT_COUNT(2, 1);
+      gt_quarter_insert(S.R[r], ((uint64_t)xh << 32) | xl);
+      // the row's m-th best may have tightened: refresh the float threshold, drop what no longer passes
+      uint32_t th = 0;
+#pragma unroll
+      for (int C = 0; C < 4; C++) {
+        const uint32_t h = __builtin_amdgcn_readlane((uint32_t)(S.R[r][7] >> 32), 16 * C + 15);
+        if (q == C) th = h;
+      }
+      const float nt = th == 0xFFFFFFFFu ? __builtin_inff() : ord2f(th);
+      S.tauf[r] = !S.rowok[r] ? -__builtin_inff() : fminf(S.tauf[r], nt);
+#pragma unroll
+      for (int t = 0; t < 4; t++) pend &= (dist[r][t] <= S.tauf[r]) ? ~0u : ~(1u << t);
+      mask = __ballot(pend != 0);
+      touched = true;
+    }
+    if (touched) {
+      // this piece's share-th best (place pplace of the list): publish it when it improved
+      uint32_t ph = (uint32_t)(S.R[r][0] >> 32);
+#pragma unroll
+      for (int j = 1; j < 8; j++) ph = (pplace >> 4) == (uint32_t)j ? (uint32_t)(S.R[r][j] >> 32) : ph;
+      uint32_t pv = 0;
+#pragma unroll
+      for (int C = 0; C < 4; C++) {
+        const uint32_t h = __builtin_amdgcn_readlane(ph, 16 * C + (int)(pplace & 15));
+        if (q == C) pv = h;
+      }
+      if ((lane & 15) == 0 && S.rowok[r] && pv < S.pub[r]) {
+        S.pub[r] = pv;
+        __hip_atomic_store(gtau_mine + (size_t)r * nsplit, pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+// this piece's lists -> partial[row][piece][0..m): place p of a list is entry p - (128 - m)
+__device__ __forceinline__ void gt_sel_write(const GtSel& S, uint64_t* partial_row0 /* [row 4q of this wave][this piece][0] */,
+                                             uint32_t m, uint32_t nsplit, int lane) {
+  const uint32_t lead = 128u - m;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    if (S.rowok[r]) {
+      uint64_t* out = partial_row0 + (size_t)r * nsplit * m;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const uint32_t p = (uint32_t)(j * 16 + (lane & 15));
+        if (p >= lead) out[p - lead] = S.R[r][j];
+      }
+    }
+  }
+}
+
 template <int METRIC, bool BF>
 __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, const float* __restrict__ bnorm, uint32_t* gtau) {
   extern __shared__ __align__(16) uint8_t smem[];
@@ -711,28 +829,16 @@ __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, cons
 #pragma unroll
   for (int ks = 0; ks < 4; ks++) af[ks] = a_load(wave * DT_AW + (lane & 15), ks * 64 + q * 16);
 
-  // lists: R[r] = row 4q + r of this wave, right-aligned in 128 places (the leading 128 - m hold key 0, which nothing
-  // displaces), so the m-th best of a row is always place 127 = register 7, lane 15 of the quarter
-  uint64_t R[4][8];
-#pragma unroll
-  for (int r = 0; r < 4; r++)
-#pragma unroll
-    for (int j = 0; j < 8; j++) R[r][j] = (uint32_t)(j * 16 + (lane & 15)) < 128u - A.m ? 0ull : KEY_INF;
+  GtSel S;
+  gt_sel_init(S, A.m, (uint32_t)(wave * DT_AW + q * 4), na_tile, lane);
   __syncthreads();
-  float an[4], tauf[4];
-  bool rowok[4];
+  float an[4];
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const uint32_t ar = wave * DT_AW + q * 4 + r;
-    an[r] = An[ar];
-    rowok[r] = ar < na_tile;
-    tauf[r] = rowok[r] ? __builtin_inff() : -__builtin_inff();             // a padding row accepts nothing
-  }
-
+  for (int r = 0; r < 4; r++) an[r] = An[wave * DT_AW + q * 4 + r];
   const uint32_t pplace = 128u - A.m + (A.m + A.nsplit - 1) / A.nsplit - 1;      // list place of the ceil(m/nsplit)-th best
   const uint32_t tau_period = GT_TAU_PERIOD * ((A.nsplit + 7) / 8);
   uint32_t tau_wait = tau_period;
-  uint32_t pub[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};       // last value published per row (lane 0 of the quarter)
+  uint32_t* gtau_mine = gtau + (a0 + wave * DT_AW + q * 4) * A.nsplit + blockIdx.y;
 
   uint4 pre0, pre1, pre2, pre3;
   float pn = 0.f;
@@ -778,22 +884,7 @@ __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, cons
   for (uint32_t i = 0; i < ntile; i++) {
     const uint64_t bt = bs + (uint64_t)i * DT_B;
     const int buf = (int)(i & 1);
-    if (--tau_wait == 0) {
-      // Every piece of a row publishes its ceil(m / nsplit)-th best.  The largest of those bounds the final m-th best from
-      // above (the pieces together hold at least m keys at or below it), so it is a valid threshold for every piece -- and
-      // much tighter than a piece's own m-th best, which has seen only 1/nsplit of the points.  A stale or missing value
-      // only lets more candidates through.
-      tau_wait = tau_period;
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const uint32_t* gp = gtau + (a0 + min((uint32_t)(wave * DT_AW + q * 4 + r), na_tile - 1u)) * A.nsplit;
-        uint32_t g = 0;
-        for (uint32_t cpiece = 0; cpiece < A.nsplit; cpiece++)
-          g = max(g, __hip_atomic_load(gp + cpiece, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        const float gf = g == 0xFFFFFFFFu ? __builtin_inff() : ord2f(g);
-        tauf[r] = rowok[r] ? fminf(tauf[r], gf) : tauf[r];
-      }
-    }
+    if (--tau_wait == 0) { tau_wait = tau_period; gt_sel_refresh(S, gtau + a0 * A.nsplit, (uint32_t)(wave * DT_AW + q * 4), na_tile, A.nsplit); }
     // No branches around these two: beyond the last tile they re-stage the piece's last row (clamped loads, SENTINEL labels)
     // into the buffer nobody reads again -- with conditional staging the compiler waited for the requests just made
     // before the first MFMA.
@@ -829,97 +920,221 @@ __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, cons
 #pragma unroll
     for (int t = 0; t < 4; t++) { const float2 m2 = Bm[buf * DT_B + t * 16 + (lane & 15)]; bn[t] = m2.x; bid[t] = __float_as_uint(m2.y); }
     float dist[4][4];
-    bool any = false;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
 #pragma unroll
       for (int t = 0; t < 4; t++) {
         if constexpr (METRIC == PANN_L2) dist[r][t] = (an[r] + bn[t]) - 2.0f * acc[t][r];
         else dist[r][t] = -acc[t][r];
-        any = any || (dist[r][t] <= tauf[r]);
       }
     }
     GT_COUNT(0, 1);
-    if (__any(any)) {
-      GT_COUNT(1, 1);
-      // rows 4c + r (c = 0..3) of this wave, one r at a time: every lane offers its first still-pending column
+    gt_select(S, dist, bid, pplace, gtau_mine, A.nsplit, lane);
+    gt_lds_barrier();
+  }
+  gt_sel_write(S, A.partial + ((a0 + wave * DT_AW + q * 4) * A.nsplit + blockIdx.y) * A.m, A.m, A.nsplit, lane);
+}
+
+// ---- the same kernel for the types whose contraction stays on the VALU (north_star: no MFMA for int8/uint8; f32 has none
+// that is exact): a 4 x 4 register tile per lane in the MFMA's own output layout (rows 4q + r, columns t*16 + (lane & 15)), so
+// the selection above is shared.  Per 16-byte chunk of the dimension a lane reads 4 A chunks (one address per quarter: LDS
+// broadcasts) and 4 B chunks and issues 64 v_dot4 (one-byte types) or 64 (sub +) fma (f32).  A sits in LDS (up to two
+// 256-byte segments of the row), B streams through the same double buffer, one segment per pipeline step.
+template <int DT, int METRIC>
+__device__ __forceinline__ void gt_chunk_accum(typename AccT<DT>::type (&acc)[4][4], const uint4 (&av)[4], const uint4 (&bv)[4]) {
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      if constexpr (DT == PANN_U8) {
+        uint32_t x = (uint32_t)acc[t][r];
+        x = __builtin_amdgcn_udot4(av[r].x, bv[t].x, x, false); x = __builtin_amdgcn_udot4(av[r].y, bv[t].y, x, false);
+        x = __builtin_amdgcn_udot4(av[r].z, bv[t].z, x, false); x = __builtin_amdgcn_udot4(av[r].w, bv[t].w, x, false);
+        acc[t][r] = (int)x;
+      } else if constexpr (DT == PANN_I8) {
+        int x = acc[t][r];
+        x = __builtin_amdgcn_sdot4((int)av[r].x, (int)bv[t].x, x, false); x = __builtin_amdgcn_sdot4((int)av[r].y, (int)bv[t].y, x, false);
+        x = __builtin_amdgcn_sdot4((int)av[r].z, (int)bv[t].z, x, false); x = __builtin_amdgcn_sdot4((int)av[r].w, (int)bv[t].w, x, false);
+        acc[t][r] = x;
+      } else {
+        const float a4[4] = {__uint_as_float(av[r].x), __uint_as_float(av[r].y), __uint_as_float(av[r].z), __uint_as_float(av[r].w)};
+        const float b4[4] = {__uint_as_float(bv[t].x), __uint_as_float(bv[t].y), __uint_as_float(bv[t].z), __uint_as_float(bv[t].w)};
+        float x = acc[t][r];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          if constexpr (METRIC == PANN_L2) { const float d = a4[e] - b4[e]; x = fmaf(d, d, x); }
+          else x = fmaf(a4[e], b4[e], x);
+        }
+        acc[t][r] = x;
+      }
+    }
+  }
+}
+// sum of squares of 16 bytes of a one-byte type
+template <int DT>
+__device__ __forceinline__ int sumsq16_i8(uint4 v) {
+  if constexpr (DT == PANN_U8) {
+    uint32_t x = __builtin_amdgcn_udot4(v.x, v.x, 0u, false); x = __builtin_amdgcn_udot4(v.y, v.y, x, false);
+    x = __builtin_amdgcn_udot4(v.z, v.z, x, false); x = __builtin_amdgcn_udot4(v.w, v.w, x, false);
+    return (int)x;
+  } else {
+    int x = __builtin_amdgcn_sdot4((int)v.x, (int)v.x, 0, false); x = __builtin_amdgcn_sdot4((int)v.y, (int)v.y, x, false);
+    x = __builtin_amdgcn_sdot4((int)v.z, (int)v.z, x, false); x = __builtin_amdgcn_sdot4((int)v.w, (int)v.w, x, false);
+    return x;
+  }
+}
+// |row|^2 of every point of a one-byte type as an int32 (exact), stored through the float pointer
+template <int DT>
+__global__ void __launch_bounds__(256) row_norms_i8_kernel(const uint8_t* points, uint32_t pstride, uint64_t n, int* out) {
+  const uint64_t row = (uint64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int c = threadIdx.x & 15;
+  int ss = 0;
+  if (row < n) for (uint32_t off = c * 16; off < pstride; off += 256) ss += sumsq16_i8<DT>(*reinterpret_cast<const uint4*>(points + row * pstride + off));
+  ss = group_sum<16>(ss);
+  if (row < n && c == 0) out[row] = ss;
+}
+
+template <int DT, int METRIC>
+__global__ void __launch_bounds__(256, 2) dense_gt_valu_kernel(DenseArgs A, const int* __restrict__ bnorm, uint32_t* gtau) {
+  using acc_t = typename AccT<DT>::type;
+  constexpr bool INTS = DT == PANN_U8 || DT == PANN_I8;
+  extern __shared__ __align__(16) uint8_t smem[];
+  const uint32_t nseg = (A.pstride + DT_SEG - 1) / DT_SEG;              // 1 or 2 (the launcher checks)
+  const uint32_t astride = nseg * DT_SEG + 16;
+  uint8_t* Bt0 = smem;                                                    // [2][64][DT_BSTRIDE]
+  float2* Bm = reinterpret_cast<float2*>(smem + 2 * GT_BT_BYTES);         // [2][64] (|b|^2 bits, id bits)
+  int* An = reinterpret_cast<int*>(Bm + 2 * DT_B);                        // [64] |a|^2 (one-byte types, L2)
+  uint8_t* At = reinterpret_cast<uint8_t*>(An + DT_A);                    // [64][astride]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4;
+  const uint64_t a0 = (uint64_t)blockIdx.x * DT_A;
+  const uint32_t na_tile = (uint32_t)min((uint64_t)DT_A, A.na - a0);
+  const uint64_t per = ((A.nb + A.nsplit - 1) / A.nsplit + DT_B - 1) / DT_B * DT_B;
+  const uint64_t bs = min(A.nb, (uint64_t)blockIdx.y * per), be = min(A.nb, (uint64_t)(blockIdx.y + 1) * per);
+  const uint32_t ntile = (uint32_t)((be - bs + DT_B - 1) / DT_B);
+  const uint32_t a_valid = A.a_ids ? A.pstride : A.dbytes;
+  auto a_load = [&](uint32_t r, uint32_t off) -> uint4 {
+    if (r >= na_tile) return make_uint4(0, 0, 0, 0);
+    const uint8_t* rp = A.a_ids ? A.points + (uint64_t)A.a_ids[a0 + r] * A.pstride : A.a_ext + (a0 + r) * A.a_stride;
+    if ((reinterpret_cast<uintptr_t>(rp) & 15) == 0) return load16_guarded(rp, off, a_valid);
+    uint8_t tmp[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) tmp[i] = (off + i < a_valid) ? rp[off + i] : (uint8_t)0;
+    uint4 v; __builtin_memcpy(&v, tmp, 16);
+    return v;
+  };
+  const int r0 = tid >> 4, c = tid & 15;
+  // the A tile -> LDS, with |a|^2 for the one-byte L2 form |a|^2 + |b|^2 - 2 a.b (all int32, exact)
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    int ss = 0;
+    for (uint32_t sg = 0; sg < nseg; sg++) {
+      const uint4 v = a_load(r0 + 16 * k, sg * DT_SEG + c * 16);
+      *reinterpret_cast<uint4*>(At + (size_t)(r0 + 16 * k) * astride + sg * DT_SEG + c * 16) = v;
+      if constexpr (INTS) ss += sumsq16_i8<DT>(v);
+    }
+    if constexpr (INTS) { ss = group_sum<16>(ss); if (c == 0) An[r0 + 16 * k] = ss; }
+  }
+  GtSel S;
+  gt_sel_init(S, A.m, (uint32_t)(wave * DT_AW + q * 4), na_tile, lane);
+  __syncthreads();
+  int an[4] = {0, 0, 0, 0};
+  if constexpr (INTS && METRIC == PANN_L2) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) an[r] = An[wave * DT_AW + q * 4 + r];
+  }
+  const uint32_t pplace = 128u - A.m + (A.m + A.nsplit - 1) / A.nsplit - 1;
+  const uint32_t tau_period = GT_TAU_PERIOD * ((A.nsplit + 7) / 8);
+  uint32_t tau_wait = tau_period;
+  uint32_t* gtau_mine = gtau + (a0 + wave * DT_AW + q * 4) * A.nsplit + blockIdx.y;
+
+  // pipeline step u = (tile u / nseg, segment u % nseg); buffer u & 1 therefore always holds the same segment.  Only the
+  // chunks that hold data are staged and multiplied (the zero padding of a row adds nothing): chunk j of segment sg is
+  // valid when sg*16 + j < nch.
+  const uint32_t nch = (A.dbytes + 15) / 16;
+  const uint32_t nunits = ntile * nseg;
+  const uint32_t last_row = (uint32_t)(be - 1);
+  const bool cv0 = (uint32_t)c < nch, cv1 = nseg == 2 && 16u + (uint32_t)c < nch;
+  const uint8_t* cb0 = A.points + min((uint32_t)c, nch - 1u) * 16u;
+  const uint8_t* cb1 = A.points + min(16u + (uint32_t)c, nch - 1u) * 16u;
+  uint4 pre0, pre1, pre2, pre3;
+  int pn = 0;
+  auto unit_bt = [&](uint32_t u) -> uint32_t { return (uint32_t)bs + (nseg == 2 ? (u >> 1) : u) * DT_B; };
+  auto load_pre = [&](uint32_t u) {          // requests only
+    const uint32_t bt = unit_bt(u);
+    const uint8_t* cb = (nseg == 2 && (u & 1)) ? cb1 : cb0;
+    pre0 = *reinterpret_cast<const uint4*>(cb + (uint64_t)min(bt + (uint32_t)r0, last_row) * A.pstride);
+    pre1 = *reinterpret_cast<const uint4*>(cb + (uint64_t)min(bt + (uint32_t)r0 + 16u, last_row) * A.pstride);
+    pre2 = *reinterpret_cast<const uint4*>(cb + (uint64_t)min(bt + (uint32_t)r0 + 32u, last_row) * A.pstride);
+    pre3 = *reinterpret_cast<const uint4*>(cb + (uint64_t)min(bt + (uint32_t)r0 + 48u, last_row) * A.pstride);
+    if (INTS && METRIC == PANN_L2) pn = bnorm[min(bt + (uint32_t)lane, last_row)];
+  };
+  auto store_pre = [&](uint32_t u) {
+    const uint32_t bt = unit_bt(u);
+    const int buf = (int)(u & 1);
+    if ((nseg == 2 && (u & 1)) ? cv1 : cv0) {
+      uint8_t* dst = Bt0 + buf * GT_BT_BYTES + (size_t)r0 * DT_BSTRIDE + c * 16;
+      *reinterpret_cast<uint4*>(dst) = pre0;
+      *reinterpret_cast<uint4*>(dst + 16 * DT_BSTRIDE) = pre1;
+      *reinterpret_cast<uint4*>(dst + 32 * DT_BSTRIDE) = pre2;
+      *reinterpret_cast<uint4*>(dst + 48 * DT_BSTRIDE) = pre3;
+    }
+    if (tid < DT_B)
+      Bm[buf * DT_B + tid] = make_float2(__int_as_float(pn), __uint_as_float((uint64_t)bt + tid < be ? bt + (uint32_t)tid : SENTINEL));
+  };
+  if (nunits > 0) {
+    load_pre(0); store_pre(0);
+    load_pre(1);
+  }
+  gt_lds_barrier();
+
+  acc_t acc[4][4];
+  for (uint32_t u = 0; u < nunits; u++) {
+    const int buf = (int)(u & 1);
+    const uint32_t sg = nseg == 2 ? (u & 1) : 0u;
+    if (sg == 0 && --tau_wait == 0) { tau_wait = tau_period; gt_sel_refresh(S, gtau + a0 * A.nsplit, (uint32_t)(wave * DT_AW + q * 4), na_tile, A.nsplit); }
+    store_pre(u + 1);                                          // (beyond the last step: the piece's last row again, into a dead buffer)
+    load_pre(u + 2);
+    if (sg == 0) {
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[t][r] = (acc_t)0;
+    }
+    const uint8_t* Bp = Bt0 + buf * GT_BT_BYTES + (size_t)(lane & 15) * DT_BSTRIDE;
+    const uint8_t* Ap = At + (size_t)(wave * DT_AW + q * 4) * astride + sg * DT_SEG;
+    const uint32_t nc = nch > sg * 16u ? min(16u, nch - sg * 16u) : 0u;
+    for (uint32_t j = 0; j < nc; j++) {
+      uint4 av[4], bv[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) av[r] = *reinterpret_cast<const uint4*>(Ap + (size_t)r * astride + j * 16);
+#pragma unroll
+      for (int t = 0; t < 4; t++) bv[t] = *reinterpret_cast<const uint4*>(Bp + (size_t)t * 16 * DT_BSTRIDE + j * 16);
+      gt_chunk_accum<DT, METRIC>(acc, av, bv);
+    }
+    if (sg == nseg - 1) {
+      int bn[4]; uint32_t bid[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) { const float2 m2 = Bm[buf * DT_B + t * 16 + (lane & 15)]; bn[t] = __float_as_int(m2.x); bid[t] = __float_as_uint(m2.y); }
+      float dist[4][4];
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        uint32_t pend = 0;
 #pragma unroll
-        for (int t = 0; t < 4; t++) pend |= (dist[r][t] <= tauf[r] && bid[t] != SENTINEL) ? (1u << t) : 0u;
-        uint64_t mask = __ballot(pend != 0);
-        bool touched = false;
-        while (mask) {
-          // every lane offers its first pending column; each quarter takes the offer of its first offering lane
-          const int t0 = __ffs(pend) - 1;
-          const float dsel = t0 == 0 ? dist[r][0] : t0 == 1 ? dist[r][1] : t0 == 2 ? dist[r][2] : dist[r][3];
-          const uint32_t isel = t0 == 0 ? bid[0] : t0 == 1 ? bid[1] : t0 == 2 ? bid[2] : bid[3];
-          const uint32_t osel = f2ord(dsel);
-          uint32_t xh = 0xFFFFFFFFu, xl = 0xFFFFFFFFu;
-          int mine = -1;
-#pragma unroll
-          for (int C = 0; C < 4; C++) {
-            const uint32_t field = (uint32_t)(mask >> (16 * C)) & 0xFFFFu;
-            const int L = 16 * C + (field ? __builtin_ctz(field) : 0);
-            const uint32_t h = field ? __builtin_amdgcn_readlane(osel, L) : 0xFFFFFFFFu;
-            const uint32_t l = field ? __builtin_amdgcn_readlane(isel, L) : 0xFFFFFFFFu;
-            if (q == C) { xh = h; xl = l; mine = field ? L : -1; }
-          }
-          if (lane == mine) pend &= pend - 1;
-#ifdef PANN_GT_COUNTERS
-          GT_COUNT(2, 1);
-          GT_COUNT(3, __popcll(__ballot((lane & 15) == 15 && ((uint64_t)xh << 32 | xl) < R[r][7])));
-#endif
-          gt_quarter_insert(R[r], ((uint64_t)xh << 32) | xl);
-          // the row's m-th best may have tightened: refresh the float threshold, drop what no longer passes
-          uint32_t th = 0;
-#pragma unroll
-          for (int C = 0; C < 4; C++) {
-            const uint32_t h = __builtin_amdgcn_readlane((uint32_t)(R[r][7] >> 32), 16 * C + 15);
-            if (q == C) th = h;
-          }
-          const float nt = th == 0xFFFFFFFFu ? __builtin_inff() : ord2f(th);
-          tauf[r] = !rowok[r] ? -__builtin_inff() : fminf(tauf[r], nt);
-#pragma unroll
-          for (int t = 0; t < 4; t++) pend &= (dist[r][t] <= tauf[r]) ? ~0u : ~(1u << t);
-          mask = __ballot(pend != 0);
-          touched = true;
-        }
-        if (touched) {
-          // this piece's share-th best (place pplace of the list): publish it when it improved
-          uint32_t ph = (uint32_t)(R[r][0] >> 32);
-#pragma unroll
-          for (int j = 1; j < 8; j++) ph = (pplace >> 4) == (uint32_t)j ? (uint32_t)(R[r][j] >> 32) : ph;
-          uint32_t pv = 0;
-#pragma unroll
-          for (int C = 0; C < 4; C++) {
-            const uint32_t h = __builtin_amdgcn_readlane(ph, 16 * C + (int)(pplace & 15));
-            if (q == C) pv = h;
-          }
-          if ((lane & 15) == 0 && rowok[r] && pv < pub[r]) {
-            pub[r] = pv;
-            __hip_atomic_store(gtau + (a0 + wave * DT_AW + q * 4 + r) * A.nsplit + blockIdx.y, pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int t = 0; t < 4; t++) {
+          if constexpr (INTS) {
+            if constexpr (METRIC == PANN_L2) dist[r][t] = (float)(an[r] + bn[t] - 2 * (int)acc[t][r]);
+            else dist[r][t] = -(float)(int)acc[t][r];
+          } else {
+            if constexpr (METRIC == PANN_L2) dist[r][t] = (float)acc[t][r];
+            else dist[r][t] = -(float)acc[t][r];
           }
         }
       }
+      GT_COUNT(0, 1);
+      gt_select(S, dist, bid, pplace, gtau_mine, A.nsplit, lane);
     }
     gt_lds_barrier();
   }
-  // ---- this piece's lists -> partial[row][piece][0..m): place p of a list is entry p - (128 - m) ----
-  const uint32_t lead = 128u - A.m;
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const uint32_t ar = wave * DT_AW + q * 4 + r;
-    if (ar < na_tile) {
-      uint64_t* out = A.partial + ((a0 + ar) * A.nsplit + blockIdx.y) * A.m;
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const uint32_t p = (uint32_t)(j * 16 + (lane & 15));
-        if (p >= lead) out[p - lead] = R[r][j];
-      }
-    }
-  }
+  gt_sel_write(S, A.partial + ((a0 + wave * DT_AW + q * 4) * A.nsplit + blockIdx.y) * A.m, A.m, A.nsplit, lane);
 }
 
 // merge the nsplit partial lists of each A row (one wave per row) and write ids / dists
@@ -960,18 +1175,37 @@ constexpr size_t GT_LDS_BYTES = 2 * (size_t)GT_BT_BYTES + 2 * DT_B * sizeof(floa
 
 bool dense_gt_eligible(const DeviceIndex& ix, uint32_t m, bool b_ids, bool segmented, int exclude_same) {
   static const bool off = getenv("PANN_GT_OLD") != nullptr;      // diagnostic A/B switch
-  return !off && m > 16 && m <= 128 && !ix.exact && (ix.dtype == PANN_F16 || ix.dtype == PANN_BF16) && ix.pstride <= 256 &&
-         !b_ids && !segmented && !exclude_same;
+  if (off || m <= 16 || m > 128 || ix.exact || b_ids || segmented || exclude_same) return false;
+  if (ix.dtype == PANN_F16 || ix.dtype == PANN_BF16) return ix.pstride <= 256;       // matrix cores, one 256-byte segment
+  return ix.pstride <= 512;                                                         // VALU register tile, up to two segments
+}
+static size_t dense_gt_lds(const DeviceIndex& ix) {
+  if (ix.dtype == PANN_F16 || ix.dtype == PANN_BF16) return GT_LDS_BYTES;
+  const size_t nseg = (ix.pstride + DT_SEG - 1) / DT_SEG;
+  return GT_LDS_BYTES + (size_t)DT_A * (nseg * DT_SEG + 16);
+}
+template <typename F>
+static auto dense_gt_pick(const DeviceIndex& ix, F&& f) {
+  const bool l2 = ix.metric == PANN_L2;
+  switch (ix.dtype) {
+    case PANN_F16: return l2 ? f(dense_gt_mfma_kernel<PANN_L2, false>) : f(dense_gt_mfma_kernel<PANN_MIPS, false>);
+    case PANN_BF16: return l2 ? f(dense_gt_mfma_kernel<PANN_L2, true>) : f(dense_gt_mfma_kernel<PANN_MIPS, true>);
+    case PANN_U8: return l2 ? f(dense_gt_valu_kernel<PANN_U8, PANN_L2>) : f(dense_gt_valu_kernel<PANN_U8, PANN_MIPS>);
+    case PANN_I8: return l2 ? f(dense_gt_valu_kernel<PANN_I8, PANN_L2>) : f(dense_gt_valu_kernel<PANN_I8, PANN_MIPS>);
+    default: return l2 ? f(dense_gt_valu_kernel<PANN_F32, PANN_L2>) : f(dense_gt_valu_kernel<PANN_F32, PANN_MIPS>);
+  }
 }
 
 // workgroups of the ground-truth launch that are resident at once (for the caller's choice of nsplit)
 uint32_t dense_gt_slots(const DeviceIndex& ix, uint32_t m) {
   if (!dense_gt_eligible(ix, m, false, false, 0)) return 256;
-  int nb = 0;
-  const void* f = ix.dtype == PANN_BF16
-      ? (ix.metric == PANN_L2 ? (const void*)dense_gt_mfma_kernel<PANN_L2, true> : (const void*)dense_gt_mfma_kernel<PANN_MIPS, true>)
-      : (ix.metric == PANN_L2 ? (const void*)dense_gt_mfma_kernel<PANN_L2, false> : (const void*)dense_gt_mfma_kernel<PANN_MIPS, false>);
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, 256, GT_LDS_BYTES) != hipSuccess || nb < 1) nb = 1;
+  const size_t lds = dense_gt_lds(ix);
+  const int nb = dense_gt_pick(ix, [&](auto kern) -> int {
+    int v = 0;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, reinterpret_cast<const void*>(kern), 256, lds) != hipSuccess || v < 1) v = 1;
+    return v;
+  });
   return 256u * (uint32_t)nb;
 }
 
@@ -1005,16 +1239,20 @@ int dense_topk_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, const u
     float* d_norm = reinterpret_cast<float*>(static_cast<uint8_t*>(ws.buf) + poff);
     uint32_t* d_gtau = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(ws.buf) + noff);      // [A row][piece]: the piece's ceil(m/nsplit)-th best so far
     PANN_HIP(hipMemsetAsync(d_gtau, 0xFF, (size_t)na * nsplit * 4, st));
-    const bool bf = ix.dtype == PANN_BF16;
-    if (ix.metric == PANN_L2) {
-      const dim3 ng((uint32_t)((nb + 15) / 16));
-      if (bf) hipLaunchKernelGGL(row_norms_kernel<true>, ng, dim3(256), 0, st, ix.points, ix.pstride, nb, d_norm);
-      else hipLaunchKernelGGL(row_norms_kernel<false>, ng, dim3(256), 0, st, ix.points, ix.pstride, nb, d_norm);
+    const dim3 ng((uint32_t)((nb + 15) / 16));
+    if (ix.metric == PANN_L2) {       // |b|^2 of every point: f32 bits for the two-byte floats, exact int32 for the one-byte types
+      if (ix.dtype == PANN_BF16) hipLaunchKernelGGL(row_norms_kernel<true>, ng, dim3(256), 0, st, ix.points, ix.pstride, nb, d_norm);
+      else if (ix.dtype == PANN_F16) hipLaunchKernelGGL(row_norms_kernel<false>, ng, dim3(256), 0, st, ix.points, ix.pstride, nb, d_norm);
+      else if (ix.dtype == PANN_U8) hipLaunchKernelGGL(row_norms_i8_kernel<PANN_U8>, ng, dim3(256), 0, st, ix.points, ix.pstride, nb, (int*)d_norm);
+      else if (ix.dtype == PANN_I8) hipLaunchKernelGGL(row_norms_i8_kernel<PANN_I8>, ng, dim3(256), 0, st, ix.points, ix.pstride, nb, (int*)d_norm);
     }
-#define CALL_GT(MT, BF) hipLaunchKernelGGL((dense_gt_mfma_kernel<MT, BF>), grid, dim3(256), GT_LDS_BYTES, st, A, (const float*)d_norm, d_gtau)
-    if (bf) { if (ix.metric == PANN_L2) CALL_GT(PANN_L2, true); else CALL_GT(PANN_MIPS, true); }
-    else { if (ix.metric == PANN_L2) CALL_GT(PANN_L2, false); else CALL_GT(PANN_MIPS, false); }
-#undef CALL_GT
+    const size_t glds = dense_gt_lds(ix);
+    dense_gt_pick(ix, [&](auto kern) -> int {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds);
+      using norm_t = std::conditional_t<std::is_invocable_v<decltype(kern), DenseArgs, const float*, uint32_t*>, const float*, const int*>;
+      hipLaunchKernelGGL(kern, grid, dim3(256), glds, st, A, (norm_t)d_norm, d_gtau);
+      return 0;
+    });
     PANN_HIP(hipGetLastError());
     hipLaunchKernelGGL(dense_merge_kernel, dim3((uint32_t)na), dim3(64), (size_t)mcap * 8, st,
                        (const uint64_t*)ws.buf, na, nsplit, m, mcap, d_out_ids, d_out_dists);

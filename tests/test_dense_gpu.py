@@ -67,6 +67,28 @@ def test_bruteforce_register_list_kernel(oracle, monkeypatch, metric, d, k, n, n
     ix.close()
 
 
+@pytest.mark.parametrize("dtype,metric,d,k,n,nq,nsplit", [
+    (np.uint8, "l2", 128, 100, 20000, 130, None), (np.uint8, "mips", 128, 100, 9000, 65, 2), (np.uint8, "l2", 300, 40, 5000, 33, None),
+    (np.int8, "mips", 200, 100, 20000, 130, None), (np.int8, "l2", 100, 17, 6000, 64, 3), (np.int8, "l2", 256, 128, 3000, 10, 1),
+    (np.float32, "l2", 96, 100, 9000, 70, None), (np.float32, "mips", 128, 37, 6000, 129, 2), (np.float32, "l2", 20, 100, 3000, 5, None),
+    (np.uint8, "l2", 128, 100, 50, 3, None), (np.float32, "l2", 65, 30, 200, 64, 1),
+])
+def test_bruteforce_register_list_kernel_valu_types(oracle, monkeypatch, dtype, metric, d, k, n, nq, nsplit):
+    """one-byte types and f32, rows <= 512 bytes, k in 17..128: dense_gt_valu_kernel (v_dot4 / fma register tile in the MFMA's
+    output layout, the same register lists); one and two 256-byte segments, rows that end inside a 16-byte chunk"""
+    if nsplit:
+        monkeypatch.setenv("PANN_GT_NSPLIT", str(nsplit))
+    X = _mk(n, d, dtype)
+    Q = _mk(nq, d, dtype, seed=4321)
+    X[n // 2] = X[n // 3]
+    ix = DeviceIndex(X, max_degree=8, metric=metric)
+    gi, gd = ix.bruteforce_knn(Q, k)
+    oi, od = oracle.bruteforce_knn(X, Q, k, metric=metric)
+    np.testing.assert_array_equal(oi, gi)
+    np.testing.assert_array_equal(od, gd)
+    ix.close()
+
+
 @pytest.mark.parametrize("dtype,metric,d", [(np.uint8, "l2", 128), (np.int8, "l2", 100), (np.float32, "mips", 200),
                                             (np.float16, "mips", 128), (np.uint8, "mips", 32)])
 def test_plain_distances(oracle, dtype, metric, d):
