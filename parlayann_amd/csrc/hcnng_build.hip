@@ -339,6 +339,25 @@ struct HBuf {   // small RAII device buffer
   int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess ? 0 : 1; }
   template <typename T> T* as() { return (T*)p; }
 };
+// The builder's scratch arrays are carved out of ONE allocation: at 10M points the forest needs ~6 GB in twenty arrays, and
+// twenty hipMalloc / hipFree pairs of that size cost more than the tree phase itself.
+struct ABuf {
+  void* p = nullptr;
+  template <typename T> T* as() { return (T*)p; }
+};
+struct Arena {
+  HBuf mem;
+  std::vector<std::pair<ABuf*, size_t>> want;
+  void add(ABuf& b, size_t bytes) { want.emplace_back(&b, (std::max<size_t>(bytes, 16) + 255) / 256 * 256); }
+  int commit() {
+    size_t tot = 0;
+    for (auto& w : want) tot += w.second;
+    if (mem.alloc(tot)) return 1;
+    size_t off = 0;
+    for (auto& w : want) { w.first->p = static_cast<uint8_t*>(mem.p) + off; off += w.second; }
+    return 0;
+  }
+};
 
 // Trees first_tree, first_tree + tree_step, ... (num_clusters of them) of the forest seeded by `seed` (tree t: mix(mix(seed + t))).
 // slab == nullptr: the edges are appended to the index's graph rows (pann_hcnng_build).  slab != nullptr (tree-parallel build over
@@ -366,25 +385,28 @@ int hcnng_build_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, uint32
   uint32_t group = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(num_clusters, (1ull << 31) / std::max<uint64_t>(n, 1)));
   if (const char* g = getenv("PANN_HCNNG_GROUP")) group = std::max<uint32_t>(1, std::min<uint32_t>(group, (uint32_t)atoi(g)));   // test hook: smaller forests
   const uint64_t gn = (uint64_t)group * n;
-  HBuf b_ids, b_new, b_first, b_scan, b_pos, b_deg, b_leaflo, b_nnids, b_nnd, b_ka, b_kb, b_par, b_rnk, b_dgr, b_tmp;
+  ABuf b_ids, b_new, b_first, b_scan, b_pos, b_deg, b_leaflo, b_nnids, b_nnd, b_ka, b_kb, b_par, b_rnk, b_dgr, b_tmp;
+  ABuf d_sc, d_tbase, d_same, d_scat, d_n0, d_loff, d_seg_b, d_seg_e;
+  Arena arena;
   size_t scan_tmp = 0, sort_tmp = 0;
   (void)rocprim::exclusive_scan(nullptr, scan_tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)gn + 1, rocprim::plus<uint32_t>(), st);
   (void)rocprim::segmented_radix_sort_keys(nullptr, sort_tmp, (uint64_t*)nullptr, (uint64_t*)nullptr, (unsigned)(n * m), (unsigned)(n / 2 + 2),
                                            (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0, 64, st);
   if (n * m >= 0xFFFFFFF0ull) { set_error("pann_hcnng_build: n too large for 32-bit edge offsets"); return PANN_ERR_BAD_ARG; }
-  if (b_ids.alloc(gn * 4) || b_new.alloc(gn * 4) || b_first.alloc((gn + 1) * 4) || b_scan.alloc((gn + 1) * 4) || b_pos.alloc(n * 4) ||
-      b_deg.alloc(n * 4) || b_leaflo.alloc(n * 4) || b_nnids.alloc(n * m * 4) || b_nnd.alloc(n * m * 4) || b_ka.alloc(n * m * 8) ||
-      b_kb.alloc(n * m * 8) || b_par.alloc(n * 4) || b_rnk.alloc(n) || b_dgr.alloc(n) || b_tmp.alloc(std::max(scan_tmp, sort_tmp) + 256)) {
-    set_error("pann_hcnng_build: hipMalloc failed"); return PANN_ERR_HIP;
-  }
+  // per-level buffers, sized once for the worst level: clusters that still split are longer than cluster_size; a tree has at
+  // most n / (cluster_size / 2) + 1 leaves only when every split is even, so the leaf arrays take the safe bound n + 1
+  const size_t ncl_cap = (size_t)(gn / cluster_size) + 2 * group + 2;
+  arena.add(b_ids, gn * 4); arena.add(b_new, gn * 4); arena.add(b_first, (gn + 1) * 4); arena.add(b_scan, (gn + 1) * 4);
+  arena.add(b_pos, n * 4); arena.add(b_deg, n * 4); arena.add(b_leaflo, n * 4); arena.add(b_nnids, n * m * 4); arena.add(b_nnd, n * m * 4);
+  arena.add(b_ka, n * m * 8); arena.add(b_kb, n * m * 8); arena.add(b_par, n * 4); arena.add(b_rnk, n); arena.add(b_dgr, n);
+  arena.add(b_tmp, std::max(scan_tmp, sort_tmp) + 256);
+  arena.add(d_sc, ncl_cap * sizeof(SplitCluster)); arena.add(d_tbase, (ncl_cap + 1) * 4); arena.add(d_same, ncl_cap * 4);
+  arena.add(d_scat, ncl_cap * sizeof(ScatterCluster)); arena.add(d_n0, ncl_cap * 4);
+  arena.add(d_loff, (n + 2) * 8); arena.add(d_seg_b, (n + 1) * 4); arena.add(d_seg_e, (n + 1) * 4);
+  if (arena.commit()) { set_error("pann_hcnng_build: hipMalloc failed"); return PANN_ERR_HIP; }
   hipLaunchKernelGGL(degree_init_kernel, dim3((uint32_t)n), dim3(64), 0, st, ix.graph, ix.gstride, b_deg.as<uint32_t>(), n);
   PANN_HIP(hipGetLastError());
 
-  // per-level buffers, sized once for the worst level: clusters that still split are longer than cluster_size
-  const size_t ncl_cap = (size_t)(gn / cluster_size) + 2 * group + 2;
-  HBuf d_sc, d_tbase, d_same, d_scat, d_n0;
-  if (d_sc.alloc(ncl_cap * sizeof(SplitCluster)) || d_tbase.alloc((ncl_cap + 1) * 4) || d_same.alloc(ncl_cap * 4) ||
-      d_scat.alloc(ncl_cap * sizeof(ScatterCluster)) || d_n0.alloc(ncl_cap * 4)) { set_error("pann_hcnng_build: hipMalloc failed"); return PANN_ERR_HIP; }
   struct Cl { uint32_t lo, len; uint64_t rnd; };
   double t_tree = 0, t_leaf = 0, t_mst = 0;
   for (uint32_t tg = 0; tg < num_clusters; tg += group) {
@@ -466,8 +488,7 @@ int hcnng_build_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, uint32
     const uint32_t nleaves = (uint32_t)leaf_off.size() - 1;
 
     // ---- all-pairs 10-NN of every leaf (device ids, no host copy) ----
-    HBuf d_loff, d_tseg, d_ta0, d_seg_b, d_seg_e;
-    if (d_loff.alloc((nleaves + 1) * 8) || d_seg_b.alloc(nleaves * 4) || d_seg_e.alloc(nleaves * 4)) { set_error("pann_hcnng_build: hipMalloc failed"); return PANN_ERR_HIP; }
+    HBuf d_tseg, d_ta0;
     PANN_HIP(hipMemcpyAsync(d_loff.p, leaf_off.data(), (nleaves + 1) * 8, hipMemcpyHostToDevice, st));
     if (leaf_knn_rows_eligible(ix, m)) {     // one-byte element types: lane-owns-row kernel (leaf_knn.hip)
       if (int rc = leaf_knn_rows_dev(ix, ws, st, ids, d_loff.as<uint64_t>(), leaf_off.data(), nleaves, m, 1, b_nnids.as<uint32_t>(), b_nnd.as<float>())) return rc;
