@@ -89,6 +89,29 @@ def test_bruteforce_register_list_kernel_valu_types(oracle, monkeypatch, dtype, 
     ix.close()
 
 
+def test_bruteforce_random_shapes(oracle, monkeypatch):
+    """seeded sweep over (type, metric, d, k, n, nq, pieces): every shape the ground-truth kernels dispatch on -- register
+    lists (k > 16), lane lists (k <= 16), one / two segments, the LDS-list fallback for long rows"""
+    rng = np.random.default_rng(20260)
+    dts = [np.uint8, np.int8, np.float16, np.float32]
+    for it in range(40):
+        dtype = dts[it % 4]
+        metric = "l2" if rng.random() < 0.6 else "mips"
+        d = int(rng.choice([8, 20, 64, 96, 100, 128, 200, 256]))
+        k = int(rng.choice([1, 10, 16, 17, 33, 64, 100, 128]))
+        n = int(rng.integers(1, 3000)); nq = int(rng.integers(1, 150))
+        monkeypatch.setenv("PANN_GT_NSPLIT", str(int(rng.integers(1, 6))))
+        X = _mk(n, d, dtype, seed=int(rng.integers(1 << 30)))
+        Q = _mk(nq, d, dtype, seed=int(rng.integers(1 << 30)))
+        ix = DeviceIndex(X, max_degree=8, metric=metric)
+        gi, gd = ix.bruteforce_knn(Q, k)
+        oi, od = oracle.bruteforce_knn(X, Q, k, metric=metric)
+        tag = f"case {it}: {np.dtype(dtype).name} {metric} d={d} k={k} n={n} nq={nq}"
+        np.testing.assert_array_equal(oi, gi, err_msg=tag)
+        np.testing.assert_array_equal(od, gd, err_msg=tag)
+        ix.close()
+
+
 @pytest.mark.parametrize("dtype,metric,d", [(np.uint8, "l2", 128), (np.int8, "l2", 100), (np.float32, "mips", 200),
                                             (np.float16, "mips", 128), (np.uint8, "mips", 32)])
 def test_plain_distances(oracle, dtype, metric, d):
