@@ -20,6 +20,13 @@
 
 #include "pann_device.h"
 
+#ifndef PANN_PRUNE_MINWAVES
+#define PANN_PRUNE_MINWAVES 6   /* the greedy prune is latency-bound: the f16 / bf16 variants take 104 VGPRs (4 waves per SIMD) unless told otherwise, 77 with this */
+#endif
+#ifndef PANN_PRUNE_PB
+#define PANN_PRUNE_PB 4   /* speculative picks per pass of the greedy prune */
+#endif
+
 namespace pann {
 
 // ---------------------------------------------------------------------------------------------
@@ -118,7 +125,7 @@ __device__ __forceinline__ void st_key(uint64_t* p, uint64_t v) {
 // walk over picks and the kill flags then cost no HBM round trip; per pick only the pick's vector and the
 // gathered vectors of the live candidates are fetched.  Longer lists (heavy re-prunes) walk the HBM copy.
 template <int DT, int METRIC, int LPC, bool NCH1>
-__global__ void __launch_bounds__(PANN_WAVE) prune_greedy_kernel(GreedyArgs A) {
+__global__ void __launch_bounds__(PANN_WAVE, PANN_PRUNE_MINWAVES) prune_greedy_kernel(GreedyArgs A) {
   const int lane = threadIdx.x;
   const uint32_t oi = blockIdx.x;
   __shared__ uint32_t Pl[PANN_WAVE];    // live candidate ids of the current tile
@@ -126,7 +133,7 @@ __global__ void __launch_bounds__(PANN_WAVE) prune_greedy_kernel(GreedyArgs A) {
   __shared__ float Pd[PANN_WAVE];       // their distance to p  (dist_pprime)
   extern __shared__ __align__(16) uint8_t smem[];
   uint4* qlds = reinterpret_cast<uint4*>(smem);
-  uint32_t* Out = reinterpret_cast<uint32_t*>(qlds + (NCH1 ? 0 : 4 * A.pv.nch * LPC)); // [R rounded to 4] selected neighbours (after 4 query slots)
+  uint32_t* Out = reinterpret_cast<uint32_t*>(qlds + (NCH1 ? 0 : PANN_PRUNE_PB * A.pv.nch * LPC)); // [R rounded to 4] selected neighbours (after the PB query slots)
   uint64_t* Ks = reinterpret_cast<uint64_t*>(Out + ((A.R + 3) & ~3u));                   // [kcap] the list, when it fits
   const uint32_t p = A.owners[oi];
   uint64_t* K = A.keys + A.seg_begin[oi];
@@ -157,7 +164,7 @@ __global__ void __launch_bounds__(PANN_WAVE) prune_greedy_kernel(GreedyArgs A) {
   // killed by the selected picks in order) are then resolved from those distances -- a quarter of the dependent
   // memory round trips of one-pick-at-a-time.  (Lists longer than kcap are walked in HBM with the same logic; the
   // exact-float-order mode keeps the plain loop.)
-  constexpr int PB = 4;
+  constexpr int PB = PANN_PRUNE_PB;
   __shared__ float Dd[PB][PANN_WAVE];
   const uint32_t qstride4 = NCH1 ? 0u : A.pv.nch * LPC;
   if (!A.pv.exact && !(A.single_pick & 1u)) {
@@ -187,7 +194,9 @@ __global__ void __launch_bounds__(PANN_WAVE) prune_greedy_kernel(GreedyArgs A) {
         load_query<DT, LPC, NCH1>(A.pv.points + (uint64_t)src * A.pv.pstride, A.dbytes, A.pv.nch, qreg[b], qlds + b * qstride4, lane);
       }
       __syncthreads();
-      bool sel[PB] = {false, false, false, false}, kills[PB] = {false, false, false, false};
+      bool sel[PB], kills[PB];
+#pragma unroll
+      for (int b = 0; b < PB; b++) { sel[b] = false; kills[b] = false; }
       bool first_tile = true;
       const uint32_t nsel0 = nsel;
       for (uint32_t t0 = ppos[0] + 1; t0 < n; t0 += PANN_WAVE) {             // :105-115
@@ -522,7 +531,7 @@ static int run_prune(const DeviceIndex& ix, PruneArgs pa, GreedyArgs ga, uint64_
   ga.keys = keys_b; ga.seg_begin = pa.seg_begin; ga.seg_end = pa.seg_end;
   { static const char* sp = getenv("PANN_PRUNE_SINGLE"); ga.single_pick = sp ? (uint32_t)atoi(sp) : 0u; }   // A/B switch: 1 one pick per pass, 2 lists in HBM
   ga.kcap = std::min<uint32_t>((max_seg_len + 63) / 64 * 64, 3072);                       // <= 24 KB of keys per wave
-  const size_t gb_lds = qb * 4 + (size_t)((ga.R + 3) & ~3u) * 4 + (size_t)ga.kcap * 8;      // 4 = PB query slots
+  const size_t gb_lds = qb * PANN_PRUNE_PB + (size_t)((ga.R + 3) & ~3u) * 4 + (size_t)ga.kcap * 8;      // PB query slots
 #define CALL_GREEDY(DT, MT, L, N1) hipLaunchKernelGGL((prune_greedy_kernel<DT, MT, L, N1>), dim3(m), dim3(PANN_WAVE), gb_lds, st, ga)
   PANN_TYPE_SWITCH(ix, CALL_GREEDY);
 #undef CALL_GREEDY
