@@ -652,9 +652,10 @@ __device__ __forceinline__ uint64_t gt_dpp64(uint64_t old, uint64_t v) {
   const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(old >> 32), (int)(uint32_t)(v >> 32), CTRL, 0xF, 0xF, false);
   return ((uint64_t)hi << 32) | lo;
 }
-__device__ __forceinline__ void gt_quarter_insert(uint64_t (&R)[8], uint64_t x) {
+template <int NR>
+__device__ __forceinline__ void gt_quarter_insert(uint64_t (&R)[NR], uint64_t x) {
 #pragma unroll
-  for (int j = 7; j >= 0; j--) {
+  for (int j = NR - 1; j >= 0; j--) {
     uint64_t prev = 0ull;
     if (j > 0) prev = gt_dpp64<0x121>(0ull, R[j - 1]);       // row_ror:1 -- lane 0 of the quarter <- lane 15 of register j-1
     prev = gt_dpp64<0x111>(prev, R[j]);                       // row_shr:1 -- lanes 1..15 <- lane-1 of register j; lane 0 keeps the carry
@@ -664,8 +665,7 @@ __device__ __forceinline__ void gt_quarter_insert(uint64_t (&R)[8], uint64_t x) 
 }
 
 #ifdef PANN_GT_COUNTERS
-// diagnostic build only (make alt ALTFLAGS=-DPANN_GT_COUNTERS): [0] tiles x waves, [1] tiles entering the insert path,
-// [2] insert rounds, [3] offers that really entered a list
+// diagnostic build only (make alt ALTFLAGS=-DPANN_GT_COUNTERS): [0] tiles x waves, [2] insert rounds
 __device__ unsigned long long gt_counters[8];
 #define GT_COUNT(i, v) do { if (lane == 0) atomicAdd(&gt_counters[i], (unsigned long long)(v)); } while (0)
 #else
@@ -676,19 +676,22 @@ __device__ unsigned long long gt_counters[8];
 // for the tile requested two iterations ahead at every tile (measured: 2.6 us per tile, the loaded HBM latency)
 __device__ __forceinline__ void gt_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// selection state of a wave in the ground-truth kernels: lists, float thresholds, what was published
+// selection state of a wave in the ground-truth / leaf kernels: lists, float thresholds, what was published.
+// NR registers of 16 places per row: 8 (m <= 128, ground truth) or 1 (m <= 16: HCNNG leaves, small-k ground truth).
+template <int NR>
 struct GtSel {
-  uint64_t R[4][8];      // R[r] = row 4q + r, right-aligned in 128 places (the leading 128 - m hold key 0, which nothing displaces):
-                         // the m-th best of a row is always place 127 = register 7, lane 15 of the quarter
+  uint64_t R[4][NR];     // R[r] = row 4q + r, right-aligned in 16*NR places (the leading ones hold key 0, which nothing displaces):
+                         // the m-th best of a row is always the last place = register NR-1, lane 15 of the quarter
   float tauf[4];         // float copy of the row's threshold (min of its own m-th best and the bound shared by the pieces)
   bool rowok[4];
   uint32_t pub[4];       // last value published per row (lane 0 of the quarter)
 };
-__device__ __forceinline__ void gt_sel_init(GtSel& S, uint32_t m, uint32_t row0, uint32_t na_tile, int lane) {
+template <int NR>
+__device__ __forceinline__ void gt_sel_init(GtSel<NR>& S, uint32_t m, uint32_t row0, uint32_t na_tile, int lane) {
 #pragma unroll
   for (int r = 0; r < 4; r++) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) S.R[r][j] = (uint32_t)(j * 16 + (lane & 15)) < 128u - m ? 0ull : KEY_INF;
+    for (int j = 0; j < NR; j++) S.R[r][j] = (uint32_t)(j * 16 + (lane & 15)) < 16u * NR - m ? 0ull : KEY_INF;
     S.rowok[r] = row0 + r < na_tile;
     S.tauf[r] = S.rowok[r] ? __builtin_inff() : -__builtin_inff();        // a padding row accepts nothing
     S.pub[r] = 0xFFFFFFFFu;
@@ -698,7 +701,8 @@ __device__ __forceinline__ void gt_sel_init(GtSel& S, uint32_t m, uint32_t row0,
 // (the pieces together hold at least m keys at or below it), so it is a valid threshold for every piece -- and much tighter
 // than a piece's own m-th best, which has seen only 1/nsplit of the points.  A stale or missing value only lets more
 // candidates through.
-__device__ __forceinline__ void gt_sel_refresh(GtSel& S, const uint32_t* gtau_rows, uint32_t row0, uint32_t na_tile, uint32_t nsplit) {
+template <int NR>
+__device__ __forceinline__ void gt_sel_refresh(GtSel<NR>& S, const uint32_t* gtau_rows, uint32_t row0, uint32_t na_tile, uint32_t nsplit) {
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const uint32_t* gp = gtau_rows + (size_t)min(row0 + r, na_tile - 1u) * nsplit;
@@ -709,10 +713,12 @@ __device__ __forceinline__ void gt_sel_refresh(GtSel& S, const uint32_t* gtau_ro
     S.tauf[r] = S.rowok[r] ? fminf(S.tauf[r], gf) : S.tauf[r];
   }
 }
-// dist[r][t]: distance of row 4q + r to the column this lane holds in column block t (id bid[t], SENTINEL: no column).
+// dist[r][t]: distance of row 4q + r to the column this lane holds in column block t (id bid[t], SENTINEL: no column;
+// a column whose id equals skip[r] is not a candidate of row r -- hcnng_index.h:153).
 // Rows one r at a time; every lane offers its first still-pending column, each quarter takes the offer of its first lane.
-__device__ __forceinline__ void gt_select(GtSel& S, const float (&dist)[4][4], const uint32_t (&bid)[4], uint32_t pplace,
-                                          uint32_t* gtau_mine /* [row 4q of this wave][this piece] */, uint32_t nsplit, int lane) {
+template <int NR>
+__device__ __forceinline__ void gt_select(GtSel<NR>& S, const float (&dist)[4][4], const uint32_t (&bid)[4], const uint32_t (&skip)[4],
+                                          uint32_t pplace, uint32_t* gtau_mine /* [row 4q of this wave][this piece] */, uint32_t nsplit, int lane) {
   const int q = lane >> 4;
   bool any = false;
 #pragma unroll
@@ -724,7 +730,7 @@ __device__ __forceinline__ void gt_select(GtSel& S, const float (&dist)[4][4], c
   for (int r = 0; r < 4; r++) {
     uint32_t pend = 0;
 #pragma unroll
-    for (int t = 0; t < 4; t++) pend |= (dist[r][t] <= S.tauf[r] && bid[t] != SENTINEL) ? (1u << t) : 0u;
+    for (int t = 0; t < 4; t++) pend |= (dist[r][t] <= S.tauf[r] && bid[t] != SENTINEL && bid[t] != skip[r]) ? (1u << t) : 0u;
     uint64_t mask = __ballot(pend != 0);
     bool touched = false;
     while (mask) {
@@ -744,12 +750,12 @@ __device__ __forceinline__ void gt_select(GtSel& S, const float (&dist)[4][4], c
       }
       if (lane == mine) pend &= pend - 1;
       GT_COUNT(2, 1);
-      gt_quarter_insert(S.R[r], ((uint64_t)xh << 32) | xl);
+      gt_quarter_insert<NR>(S.R[r], ((uint64_t)xh << 32) | xl);
       // the row's m-th best may have tightened: refresh the float threshold, drop what no longer passes
       uint32_t th = 0;
 #pragma unroll
       for (int C = 0; C < 4; C++) {
-        const uint32_t h = __builtin_amdgcn_readlane((uint32_t)(S.R[r][7] >> 32), 16 * C + 15);
+        const uint32_t h = __builtin_amdgcn_readlane((uint32_t)(S.R[r][NR - 1] >> 32), 16 * C + 15);
         if (q == C) th = h;
       }
       const float nt = th == 0xFFFFFFFFu ? __builtin_inff() : ord2f(th);
@@ -759,11 +765,11 @@ __device__ __forceinline__ void gt_select(GtSel& S, const float (&dist)[4][4], c
       mask = __ballot(pend != 0);
       touched = true;
     }
-    if (touched) {
+    if (touched) {        // (also with a single piece: a null check here made hipcc keep the lists in scratch memory)
       // this piece's share-th best (place pplace of the list): publish it when it improved
       uint32_t ph = (uint32_t)(S.R[r][0] >> 32);
 #pragma unroll
-      for (int j = 1; j < 8; j++) ph = (pplace >> 4) == (uint32_t)j ? (uint32_t)(S.R[r][j] >> 32) : ph;
+      for (int j = 1; j < NR; j++) ph = (pplace >> 4) == (uint32_t)j ? (uint32_t)(S.R[r][j] >> 32) : ph;
       uint32_t pv = 0;
 #pragma unroll
       for (int C = 0; C < 4; C++) {
@@ -777,16 +783,17 @@ __device__ __forceinline__ void gt_select(GtSel& S, const float (&dist)[4][4], c
     }
   }
 }
-// this piece's lists -> partial[row][piece][0..m): place p of a list is entry p - (128 - m)
-__device__ __forceinline__ void gt_sel_write(const GtSel& S, uint64_t* partial_row0 /* [row 4q of this wave][this piece][0] */,
+// this piece's lists -> partial[row][piece][0..m): place p of a list is entry p - (16*NR - m)
+template <int NR>
+__device__ __forceinline__ void gt_sel_write(const GtSel<NR>& S, uint64_t* partial_row0 /* [row 4q of this wave][this piece][0] */,
                                              uint32_t m, uint32_t nsplit, int lane) {
-  const uint32_t lead = 128u - m;
+  const uint32_t lead = 16u * NR - m;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     if (S.rowok[r]) {
       uint64_t* out = partial_row0 + (size_t)r * nsplit * m;
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
+      for (int j = 0; j < NR; j++) {
         const uint32_t p = (uint32_t)(j * 16 + (lane & 15));
         if (p >= lead) out[p - lead] = S.R[r][j];
       }
@@ -794,7 +801,7 @@ __device__ __forceinline__ void gt_sel_write(const GtSel& S, uint64_t* partial_r
   }
 }
 
-template <int METRIC, bool BF>
+template <int METRIC, bool BF, int NR>
 __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, const float* __restrict__ bnorm, uint32_t* gtau) {
   extern __shared__ __align__(16) uint8_t smem[];
   uint8_t* Bt0 = smem;                                                    // [2][64][DT_BSTRIDE]
@@ -829,13 +836,14 @@ __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, cons
 #pragma unroll
   for (int ks = 0; ks < 4; ks++) af[ks] = a_load(wave * DT_AW + (lane & 15), ks * 64 + q * 16);
 
-  GtSel S;
-  gt_sel_init(S, A.m, (uint32_t)(wave * DT_AW + q * 4), na_tile, lane);
+  GtSel<NR> S;
+  gt_sel_init<NR>(S, A.m, (uint32_t)(wave * DT_AW + q * 4), na_tile, lane);
+  const uint32_t skip[4] = {SENTINEL, SENTINEL, SENTINEL, SENTINEL};
   __syncthreads();
   float an[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) an[r] = An[wave * DT_AW + q * 4 + r];
-  const uint32_t pplace = 128u - A.m + (A.m + A.nsplit - 1) / A.nsplit - 1;      // list place of the ceil(m/nsplit)-th best
+  const uint32_t pplace = 16u * NR - A.m + (A.m + A.nsplit - 1) / A.nsplit - 1;   // list place of the ceil(m/nsplit)-th best
   const uint32_t tau_period = GT_TAU_PERIOD * ((A.nsplit + 7) / 8);
   uint32_t tau_wait = tau_period;
   uint32_t* gtau_mine = gtau + (a0 + wave * DT_AW + q * 4) * A.nsplit + blockIdx.y;
@@ -850,13 +858,13 @@ __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, cons
   const uint32_t nchunk = A.pstride >> 4;
   const bool cvalid = (uint32_t)c < nchunk;
   const uint8_t* cbase = A.points + min((uint32_t)c, nchunk - 1u) * 16u;
-  const uint32_t last_row = (uint32_t)(be - 1);                    // be > bs wherever a load is issued; ids are 32-bit
+  const uint32_t last_row = (uint32_t)(be - 1);                    // be > bs wherever a load is issued; positions are 32-bit
   // (four named registers, not an array: as an array the compiler kept the tile in scratch memory)
-  auto brow = [&](uint64_t bt, int k) -> const uint4* {
-    return reinterpret_cast<const uint4*>(cbase + (uint64_t)min((uint32_t)bt + (uint32_t)(r0 + 16 * k), last_row) * A.pstride);
-  };
   auto load_pre = [&](uint64_t bt) {          // requests only: nothing here may depend on the loaded values
-    pre0 = *brow(bt, 0); pre1 = *brow(bt, 1); pre2 = *brow(bt, 2); pre3 = *brow(bt, 3);
+    pre0 = *reinterpret_cast<const uint4*>(cbase + (uint64_t)min((uint32_t)bt + (uint32_t)r0, last_row) * A.pstride);
+    pre1 = *reinterpret_cast<const uint4*>(cbase + (uint64_t)min((uint32_t)bt + (uint32_t)r0 + 16u, last_row) * A.pstride);
+    pre2 = *reinterpret_cast<const uint4*>(cbase + (uint64_t)min((uint32_t)bt + (uint32_t)r0 + 32u, last_row) * A.pstride);
+    pre3 = *reinterpret_cast<const uint4*>(cbase + (uint64_t)min((uint32_t)bt + (uint32_t)r0 + 48u, last_row) * A.pstride);
     if (METRIC == PANN_L2) pn = bnorm[min((uint32_t)bt + (uint32_t)lane, last_row)];       // every wave: no branch around a load
   };
   auto store_pre = [&](int buf, uint64_t bt) {
@@ -884,8 +892,11 @@ __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, cons
   for (uint32_t i = 0; i < ntile; i++) {
     const uint64_t bt = bs + (uint64_t)i * DT_B;
     const int buf = (int)(i & 1);
-    if (--tau_wait == 0) { tau_wait = tau_period; gt_sel_refresh(S, gtau + a0 * A.nsplit, (uint32_t)(wave * DT_AW + q * 4), na_tile, A.nsplit); }
-    // No branches around these two: beyond the last tile they re-stage the piece's last row (clamped loads, SENTINEL labels)
+    if (A.nsplit > 1 && --tau_wait == 0) {
+      tau_wait = tau_period;
+      gt_sel_refresh<NR>(S, gtau + a0 * A.nsplit, (uint32_t)(wave * DT_AW + q * 4), na_tile, A.nsplit);
+    }
+    // No branches around these: beyond the last tile they re-stage the piece's last row (clamped loads, SENTINEL labels)
     // into the buffer nobody reads again -- with conditional staging the compiler waited for the requests just made
     // before the first MFMA.
     store_pre(buf ^ 1, bt + DT_B);                             // tile i+1 (requested one iteration ago) -> the other buffer
@@ -896,22 +907,20 @@ __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, cons
     const uint8_t* Bt = Bt0 + buf * GT_BT_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) {      // always the 4 k-steps of a 256-byte row: bytes beyond the row are zero in both tiles
-      {
-        const uint32_t koff = ks * 64 + q * 16;
-        if constexpr (BF) {
-          mf_bf8 a8; __builtin_memcpy(&a8, &af[ks], 16);
+      const uint32_t koff = ks * 64 + q * 16;
+      if constexpr (BF) {
+        mf_bf8 a8; __builtin_memcpy(&a8, &af[ks], 16);
 #pragma unroll
-          for (int t = 0; t < 4; t++) {
-            const mf_bf8 b8 = *reinterpret_cast<const mf_bf8*>(Bt + (size_t)(t * 16 + (lane & 15)) * DT_BSTRIDE + koff);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, acc[t], 0, 0, 0);
-          }
-        } else {
-          mf_half8 a8; __builtin_memcpy(&a8, &af[ks], 16);
+        for (int t = 0; t < 4; t++) {
+          const mf_bf8 b8 = *reinterpret_cast<const mf_bf8*>(Bt + (size_t)(t * 16 + (lane & 15)) * DT_BSTRIDE + koff);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, acc[t], 0, 0, 0);
+        }
+      } else {
+        mf_half8 a8; __builtin_memcpy(&a8, &af[ks], 16);
 #pragma unroll
-          for (int t = 0; t < 4; t++) {
-            const mf_half8 b8 = *reinterpret_cast<const mf_half8*>(Bt + (size_t)(t * 16 + (lane & 15)) * DT_BSTRIDE + koff);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, b8, acc[t], 0, 0, 0);
-          }
+        for (int t = 0; t < 4; t++) {
+          const mf_half8 b8 = *reinterpret_cast<const mf_half8*>(Bt + (size_t)(t * 16 + (lane & 15)) * DT_BSTRIDE + koff);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, b8, acc[t], 0, 0, 0);
         }
       }
     }
@@ -929,10 +938,10 @@ __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, cons
       }
     }
     GT_COUNT(0, 1);
-    gt_select(S, dist, bid, pplace, gtau_mine, A.nsplit, lane);
+    gt_select<NR>(S, dist, bid, skip, pplace, gtau_mine, A.nsplit, lane);
     gt_lds_barrier();
   }
-  gt_sel_write(S, A.partial + ((a0 + wave * DT_AW + q * 4) * A.nsplit + blockIdx.y) * A.m, A.m, A.nsplit, lane);
+  gt_sel_write<NR>(S, A.partial + ((a0 + wave * DT_AW + q * 4) * A.nsplit + blockIdx.y) * A.m, A.m, A.nsplit, lane);
 }
 
 // ---- the same kernel for the types whose contraction stays on the VALU (north_star: no MFMA for int8/uint8; f32 has none
@@ -994,7 +1003,7 @@ __global__ void __launch_bounds__(256) row_norms_i8_kernel(const uint8_t* points
   if (row < n && c == 0) out[row] = ss;
 }
 
-template <int DT, int METRIC>
+template <int DT, int METRIC, int NR>
 __global__ void __launch_bounds__(256, 2) dense_gt_valu_kernel(DenseArgs A, const int* __restrict__ bnorm, uint32_t* gtau) {
   using acc_t = typename AccT<DT>::type;
   constexpr bool INTS = DT == PANN_U8 || DT == PANN_I8;
@@ -1034,15 +1043,16 @@ __global__ void __launch_bounds__(256, 2) dense_gt_valu_kernel(DenseArgs A, cons
     }
     if constexpr (INTS) { ss = group_sum<16>(ss); if (c == 0) An[r0 + 16 * k] = ss; }
   }
-  GtSel S;
-  gt_sel_init(S, A.m, (uint32_t)(wave * DT_AW + q * 4), na_tile, lane);
+  GtSel<NR> S;
+  gt_sel_init<NR>(S, A.m, (uint32_t)(wave * DT_AW + q * 4), na_tile, lane);
   __syncthreads();
   int an[4] = {0, 0, 0, 0};
   if constexpr (INTS && METRIC == PANN_L2) {
 #pragma unroll
     for (int r = 0; r < 4; r++) an[r] = An[wave * DT_AW + q * 4 + r];
   }
-  const uint32_t pplace = 128u - A.m + (A.m + A.nsplit - 1) / A.nsplit - 1;
+  const uint32_t pplace = 16u * NR - A.m + (A.m + A.nsplit - 1) / A.nsplit - 1;
+  const uint32_t skip[4] = {SENTINEL, SENTINEL, SENTINEL, SENTINEL};
   const uint32_t tau_period = GT_TAU_PERIOD * ((A.nsplit + 7) / 8);
   uint32_t tau_wait = tau_period;
   uint32_t* gtau_mine = gtau + (a0 + wave * DT_AW + q * 4) * A.nsplit + blockIdx.y;
@@ -1091,7 +1101,7 @@ __global__ void __launch_bounds__(256, 2) dense_gt_valu_kernel(DenseArgs A, cons
   for (uint32_t u = 0; u < nunits; u++) {
     const int buf = (int)(u & 1);
     const uint32_t sg = nseg == 2 ? (u & 1) : 0u;
-    if (sg == 0 && --tau_wait == 0) { tau_wait = tau_period; gt_sel_refresh(S, gtau + a0 * A.nsplit, (uint32_t)(wave * DT_AW + q * 4), na_tile, A.nsplit); }
+    if (sg == 0 && A.nsplit > 1 && --tau_wait == 0) { tau_wait = tau_period; gt_sel_refresh<NR>(S, gtau + a0 * A.nsplit, (uint32_t)(wave * DT_AW + q * 4), na_tile, A.nsplit); }
     store_pre(u + 1);                                          // (beyond the last step: the piece's last row again, into a dead buffer)
     load_pre(u + 2);
     if (sg == 0) {
@@ -1130,11 +1140,11 @@ __global__ void __launch_bounds__(256, 2) dense_gt_valu_kernel(DenseArgs A, cons
         }
       }
       GT_COUNT(0, 1);
-      gt_select(S, dist, bid, pplace, gtau_mine, A.nsplit, lane);
+      gt_select<NR>(S, dist, bid, skip, pplace, gtau_mine, A.nsplit, lane);
     }
     gt_lds_barrier();
   }
-  gt_sel_write(S, A.partial + ((a0 + wave * DT_AW + q * 4) * A.nsplit + blockIdx.y) * A.m, A.m, A.nsplit, lane);
+  gt_sel_write<NR>(S, A.partial + ((a0 + wave * DT_AW + q * 4) * A.nsplit + blockIdx.y) * A.m, A.m, A.nsplit, lane);
 }
 
 // merge the nsplit partial lists of each A row (one wave per row) and write ids / dists
@@ -1173,11 +1183,15 @@ __global__ void __launch_bounds__(64) dense_merge_kernel(const uint64_t* partial
 
 constexpr size_t GT_LDS_BYTES = 2 * (size_t)GT_BT_BYTES + 2 * DT_B * sizeof(float2) + DT_A * sizeof(float);
 
+// external / id'd A rows against the contiguous range of all points (ground truth), any supported type, m <= 128.
+// (The HCNNG leaf form -- rows gathered by id, ~1000 columns per row, m = 10 -- was tried on these kernels and lost to the
+// lane-list kernels above, 0.167 s vs 0.121 s for 30 trees over 1M x 128 fp16: a row sees so few columns that 5.6 % of them
+// enter its list, and 64 lane-owned lists take that in parallel where the quarter lists take four at a time.)
 bool dense_gt_eligible(const DeviceIndex& ix, uint32_t m, bool b_ids, bool segmented, int exclude_same) {
   static const bool off = getenv("PANN_GT_OLD") != nullptr;      // diagnostic A/B switch
-  if (off || m <= 16 || m > 128 || ix.exact || b_ids || segmented || exclude_same) return false;
-  if (ix.dtype == PANN_F16 || ix.dtype == PANN_BF16) return ix.pstride <= 256;       // matrix cores, one 256-byte segment
-  return ix.pstride <= 512;                                                         // VALU register tile, up to two segments
+  if (off || m == 0 || m > 128 || ix.exact || b_ids || segmented || exclude_same) return false;
+  const bool twobyte = ix.dtype == PANN_F16 || ix.dtype == PANN_BF16;
+  return twobyte ? ix.pstride <= 256 : ix.pstride <= 512;        // matrix cores: one 256-byte segment; VALU register tile: two
 }
 static size_t dense_gt_lds(const DeviceIndex& ix) {
   if (ix.dtype == PANN_F16 || ix.dtype == PANN_BF16) return GT_LDS_BYTES;
@@ -1185,22 +1199,30 @@ static size_t dense_gt_lds(const DeviceIndex& ix) {
   return GT_LDS_BYTES + (size_t)DT_A * (nseg * DT_SEG + 16);
 }
 template <typename F>
-static auto dense_gt_pick(const DeviceIndex& ix, F&& f) {
-  const bool l2 = ix.metric == PANN_L2;
+static int dense_gt_pick(const DeviceIndex& ix, uint32_t m, F&& f) {
+  const bool l2 = ix.metric == PANN_L2, small = m <= 16;
+#define GT_MF(BF)                                                                                                                   \
+  (small ? (l2 ? f(dense_gt_mfma_kernel<PANN_L2, BF, 1>) : f(dense_gt_mfma_kernel<PANN_MIPS, BF, 1>))                                \
+         : (l2 ? f(dense_gt_mfma_kernel<PANN_L2, BF, 8>) : f(dense_gt_mfma_kernel<PANN_MIPS, BF, 8>)))
+#define GT_VA(DT)                                                                                                                   \
+  (small ? (l2 ? f(dense_gt_valu_kernel<DT, PANN_L2, 1>) : f(dense_gt_valu_kernel<DT, PANN_MIPS, 1>))                                \
+         : (l2 ? f(dense_gt_valu_kernel<DT, PANN_L2, 8>) : f(dense_gt_valu_kernel<DT, PANN_MIPS, 8>)))
   switch (ix.dtype) {
-    case PANN_F16: return l2 ? f(dense_gt_mfma_kernel<PANN_L2, false>) : f(dense_gt_mfma_kernel<PANN_MIPS, false>);
-    case PANN_BF16: return l2 ? f(dense_gt_mfma_kernel<PANN_L2, true>) : f(dense_gt_mfma_kernel<PANN_MIPS, true>);
-    case PANN_U8: return l2 ? f(dense_gt_valu_kernel<PANN_U8, PANN_L2>) : f(dense_gt_valu_kernel<PANN_U8, PANN_MIPS>);
-    case PANN_I8: return l2 ? f(dense_gt_valu_kernel<PANN_I8, PANN_L2>) : f(dense_gt_valu_kernel<PANN_I8, PANN_MIPS>);
-    default: return l2 ? f(dense_gt_valu_kernel<PANN_F32, PANN_L2>) : f(dense_gt_valu_kernel<PANN_F32, PANN_MIPS>);
+    case PANN_F16: return GT_MF(false);
+    case PANN_BF16: return GT_MF(true);
+    case PANN_U8: return GT_VA(PANN_U8);
+    case PANN_I8: return GT_VA(PANN_I8);
+    default: return GT_VA(PANN_F32);
   }
+#undef GT_MF
+#undef GT_VA
 }
 
 // workgroups of the ground-truth launch that are resident at once (for the caller's choice of nsplit)
 uint32_t dense_gt_slots(const DeviceIndex& ix, uint32_t m) {
   if (!dense_gt_eligible(ix, m, false, false, 0)) return 256;
   const size_t lds = dense_gt_lds(ix);
-  const int nb = dense_gt_pick(ix, [&](auto kern) -> int {
+  const int nb = dense_gt_pick(ix, m, [&](auto kern) -> int {
     int v = 0;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, reinterpret_cast<const void*>(kern), 256, lds) != hipSuccess || v < 1) v = 1;
@@ -1233,21 +1255,22 @@ int dense_topk_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, const u
   if (dense_gt_eligible(ix, m, d_b_ids != nullptr, d_a_off || d_b_off || d_tile_seg || d_tile_a0, exclude_same)) {
     // register-list ground-truth kernel; |b|^2 of every point first (after the partial lists in the workspace)
     const size_t poff = (pbytes + 255) / 256 * 256;
-    const size_t noff = poff + ((size_t)nb * 4 + 255) / 256 * 256;
+    const uint64_t nnorm = nb;
+    const size_t noff = poff + ((size_t)nnorm * 4 + 255) / 256 * 256;
     if (int rc = ws.ensure(noff + (size_t)na * nsplit * 4 + 256)) return rc;
     A.partial = (uint64_t*)ws.buf;
     float* d_norm = reinterpret_cast<float*>(static_cast<uint8_t*>(ws.buf) + poff);
     uint32_t* d_gtau = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(ws.buf) + noff);      // [A row][piece]: the piece's ceil(m/nsplit)-th best so far
     PANN_HIP(hipMemsetAsync(d_gtau, 0xFF, (size_t)na * nsplit * 4, st));
-    const dim3 ng((uint32_t)((nb + 15) / 16));
+    const dim3 ng((uint32_t)((nnorm + 15) / 16));
     if (ix.metric == PANN_L2) {       // |b|^2 of every point: f32 bits for the two-byte floats, exact int32 for the one-byte types
-      if (ix.dtype == PANN_BF16) hipLaunchKernelGGL(row_norms_kernel<true>, ng, dim3(256), 0, st, ix.points, ix.pstride, nb, d_norm);
-      else if (ix.dtype == PANN_F16) hipLaunchKernelGGL(row_norms_kernel<false>, ng, dim3(256), 0, st, ix.points, ix.pstride, nb, d_norm);
-      else if (ix.dtype == PANN_U8) hipLaunchKernelGGL(row_norms_i8_kernel<PANN_U8>, ng, dim3(256), 0, st, ix.points, ix.pstride, nb, (int*)d_norm);
-      else if (ix.dtype == PANN_I8) hipLaunchKernelGGL(row_norms_i8_kernel<PANN_I8>, ng, dim3(256), 0, st, ix.points, ix.pstride, nb, (int*)d_norm);
+      if (ix.dtype == PANN_BF16) hipLaunchKernelGGL(row_norms_kernel<true>, ng, dim3(256), 0, st, ix.points, ix.pstride, nnorm, d_norm);
+      else if (ix.dtype == PANN_F16) hipLaunchKernelGGL(row_norms_kernel<false>, ng, dim3(256), 0, st, ix.points, ix.pstride, nnorm, d_norm);
+      else if (ix.dtype == PANN_U8) hipLaunchKernelGGL(row_norms_i8_kernel<PANN_U8>, ng, dim3(256), 0, st, ix.points, ix.pstride, nnorm, (int*)d_norm);
+      else if (ix.dtype == PANN_I8) hipLaunchKernelGGL(row_norms_i8_kernel<PANN_I8>, ng, dim3(256), 0, st, ix.points, ix.pstride, nnorm, (int*)d_norm);
     }
     const size_t glds = dense_gt_lds(ix);
-    dense_gt_pick(ix, [&](auto kern) -> int {
+    dense_gt_pick(ix, m, [&](auto kern) -> int {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds);
       using norm_t = std::conditional_t<std::is_invocable_v<decltype(kern), DenseArgs, const float*, uint32_t*>, const float*, const int*>;
       hipLaunchKernelGGL(kern, grid, dim3(256), glds, st, A, (norm_t)d_norm, d_gtau);

@@ -22,5 +22,5 @@ lib.pann_debug_gt_counters(out, 1)
 ix.bruteforce_knn(Q, k)
 lib.pann_debug_gt_counters(out, 1)
 c = list(out)
-print(f"nsplit={os.environ.get('PANN_GT_NSPLIT', 'auto')}: wave-tiles {c[0]}, entering the insert path {c[1]} ({c[1] / max(c[0], 1):.3f}), "
-      f"rounds {c[2]} ({c[2] / max(c[0], 1):.3f}/wave-tile), real inserts {c[3]} ({c[3] / nq:.0f}/query)")
+print(f"nsplit={os.environ.get('PANN_GT_NSPLIT', 'auto')}: wave-tiles {c[0]}, "
+      f"rounds {c[2]} ({c[2] / max(c[0], 1):.3f}/wave-tile)")
