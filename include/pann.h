@@ -112,6 +112,12 @@ int pann_device_count(void);
 int pann_index_create(pann_index** out, const void* points, uint64_t n, uint32_t d, int dtype,
                       uint64_t row_stride_bytes, int metric, const uint32_t* graph,
                       uint32_t max_deg, int device);
+/* Streaming form of the same (the reference's loaders read a whole file into host memory first --
+ * point_range.h:74-117, graph.h:147-232; a shard of a 100M-point file need not exist on the host at once): an index of n zero
+ * points and an empty graph, then any number of row ranges.  rows: nrows x d elements with row stride row_stride_bytes; the
+ * range [first_row, first_row + nrows) must lie inside the index.  Graph rows stream through pann_index_update_rows. */
+int pann_index_create_empty(pann_index** out, uint64_t n, uint32_t d, int dtype, int metric, uint32_t max_deg, int device);
+int pann_index_upload_points(pann_index* idx, uint64_t first_row, const void* rows, uint64_t nrows, uint64_t row_stride_bytes);
 void pann_index_destroy(pann_index* idx);
 
 uint64_t pann_index_size(const pann_index* idx);

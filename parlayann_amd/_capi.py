@@ -59,6 +59,8 @@ SIGNATURES = {
     "pann_device_count": (C.c_int, []),
     "pann_index_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_uint32, C.c_int,
                                     C.c_uint64, C.c_int, C.c_void_p, C.c_uint32, C.c_int]),
+    "pann_index_create_empty": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_int]),
+    "pann_index_upload_points": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64]),
     "pann_index_destroy": (None, [C.c_void_p]),
     "pann_index_size": (C.c_uint64, [C.c_void_p]),
     "pann_index_dims": (C.c_uint32, [C.c_void_p]),

@@ -181,10 +181,43 @@ int pann_device_count(void) {
   return n;
 }
 
+static int index_create_impl(pann_index** out, const void* points, uint64_t n, uint32_t d, int dtype,
+                             uint64_t row_stride_bytes, int metric, const uint32_t* graph,
+                             uint32_t max_deg, int device);
+
 int pann_index_create(pann_index** out, const void* points, uint64_t n, uint32_t d, int dtype,
                       uint64_t row_stride_bytes, int metric, const uint32_t* graph,
                       uint32_t max_deg, int device) {
-  if (!out || !points || n == 0 || d == 0) { set_error("pann_index_create: null/empty argument"); return PANN_ERR_BAD_ARG; }
+  if (!points) { set_error("pann_index_create: null/empty argument"); return PANN_ERR_BAD_ARG; }
+  return index_create_impl(out, points, n, d, dtype, row_stride_bytes, metric, graph, max_deg, device);
+}
+
+int pann_index_create_empty(pann_index** out, uint64_t n, uint32_t d, int dtype, int metric, uint32_t max_deg, int device) {
+  return index_create_impl(out, nullptr, n, d, dtype, (uint64_t)d * esize_of(dtype), metric, nullptr, max_deg, device);
+}
+
+int pann_index_upload_points(pann_index* idx, uint64_t first_row, const void* rows, uint64_t nrows, uint64_t row_stride_bytes) {
+  if (int rc = check_idx(idx, "pann_index_upload_points")) return rc;
+  if (nrows == 0) return PANN_OK;
+  const DeviceIndex& ix = idx->ix;
+  if (!rows) { set_error("pann_index_upload_points: null argument"); return PANN_ERR_BAD_ARG; }
+  if (first_row > ix.n || nrows > ix.n - first_row) { set_error("pann_index_upload_points: row range outside the index"); return PANN_ERR_BAD_ARG; }
+  if (row_stride_bytes < ix.dbytes) { set_error("pann_index_upload_points: row stride smaller than a row"); return PANN_ERR_BAD_ARG; }
+  DeviceGuard g(idx->device);
+  PANN_HIP(hipStreamSynchronize(idx->stream));                  // no search may be reading the rows being replaced
+  const uint64_t slice = std::max<uint64_t>(1, (1ull << 30) / std::max<uint64_t>(row_stride_bytes, 1));
+  for (uint64_t r0 = 0; r0 < nrows; r0 += slice) {
+    const uint64_t cnt = std::min(slice, nrows - r0);
+    PANN_HIP(hipMemcpy2D(ix.points + (first_row + r0) * ix.pstride, ix.pstride, (const uint8_t*)rows + r0 * row_stride_bytes,
+                         row_stride_bytes, ix.dbytes, cnt, hipMemcpyHostToDevice));
+  }
+  return PANN_OK;
+}
+
+static int index_create_impl(pann_index** out, const void* points, uint64_t n, uint32_t d, int dtype,
+                             uint64_t row_stride_bytes, int metric, const uint32_t* graph,
+                             uint32_t max_deg, int device) {
+  if (!out || n == 0 || d == 0) { set_error("pann_index_create: null/empty argument"); return PANN_ERR_BAD_ARG; }
   const uint32_t es = esize_of(dtype);
   if (es == 0) { set_error("pann_index_create: unknown dtype"); return PANN_ERR_BAD_ARG; }
   if (metric != PANN_L2 && metric != PANN_MIPS) { set_error("pann_index_create: unknown metric"); return PANN_ERR_BAD_ARG; }
@@ -212,7 +245,7 @@ int pann_index_create(pann_index** out, const void* points, uint64_t n, uint32_t
   // points: strided copy into the zero-padded device rows
   if ((e = hipMemsetAsync(ix.points, 0, n * (size_t)ix.pstride, idx->stream)) != hipSuccess) return fail(hip_fail(e, "hipMemset(points)"));
   if ((e = hipStreamSynchronize(idx->stream)) != hipSuccess) return fail(hip_fail(e, "sync"));
-  {
+  if (points) {
     const uint64_t slice = std::max<uint64_t>(1, (1ull << 30) / std::max<uint64_t>(row_stride_bytes, 1));
     for (uint64_t r0 = 0; r0 < n; r0 += slice) {
       const uint64_t cnt = std::min(slice, n - r0);

@@ -68,6 +68,71 @@ class DeviceIndex:
         if exact_float_order:      # validation mode: bit-identical float results on real-valued data
             check(lib.pann_index_set_exact_float_order(h, 1))
 
+    @classmethod
+    def from_files(cls, points_path, dtype, graph_path=None, max_degree=None, metric="Euclidian", device=0, rows=None,
+                   chunk_bytes=256 << 20, exact_float_order=False):
+        """Stream a reference-format vector file (point_range.h:74-117: [n:u32][d:u32][rows]) -- and, optionally, a graph file
+        (graph.h:147-232: [n:u32][maxDeg:u32][deg[n]][edges]) -- onto the device in chunks of about chunk_bytes, without
+        holding either whole on the host.  rows = (lo, hi): only that range of the vector file becomes the index (row lo is
+        vertex 0: one shard of a sharded index; the graph file, if given, must describe exactly these hi - lo vertices)."""
+        lib = _capi.load()
+        dt = np.dtype(dtype)
+        if dt not in _DT:
+            raise ValueError("dtype must be uint8/int8/float32/float16/bfloat16 (parlayann_amd.bfloat16)")
+        with open(points_path, "rb") as f:
+            n_file, d = (int(v) for v in np.fromfile(f, dtype=np.uint32, count=2))
+        lo, hi = (0, n_file) if rows is None else (int(rows[0]), int(rows[1]))
+        if not (0 <= lo < hi <= n_file):
+            raise ValueError(f"rows {rows} outside the {n_file} rows of {points_path}")
+        n = hi - lo
+        gf = None
+        if graph_path is not None:
+            gf = open(graph_path, "rb")
+            gn, gmax = (int(v) for v in np.fromfile(gf, dtype=np.uint32, count=2))
+            if gn != n:
+                gf.close()
+                raise ValueError(f"graph file has {gn} vertices, the index {n}")
+            max_degree = gmax
+        if max_degree is None:
+            raise ValueError("give a graph file or max_degree")
+        self = cls.__new__(cls)
+        self.n, self.d, self.max_degree = n, d, int(max_degree)
+        self.dtype, self.metric = dt, _metric_code(metric)
+        h = C.c_void_p()
+        check(lib.pann_index_create_empty(C.byref(h), n, d, _DT[dt], self.metric, self.max_degree, device))
+        self._h, self._lib = h, lib
+        try:
+            row_bytes = d * dt.itemsize
+            step = max(1, int(chunk_bytes) // row_bytes)
+            mm = np.memmap(points_path, dtype=np.uint8, mode="r", offset=8 + lo * row_bytes, shape=(n, row_bytes))
+            for a in range(0, n, step):
+                chunk = np.ascontiguousarray(mm[a:min(a + step, n)])
+                check(lib.pann_index_upload_points(h, a, _ptr(chunk), len(chunk), row_bytes))
+            del mm
+            if gf is not None:
+                deg = np.fromfile(gf, dtype=np.uint32, count=n)
+                if deg.size != n or (deg > self.max_degree).any():
+                    raise ValueError("graph file: bad degree array")
+                gstep = max(1, int(chunk_bytes) // (4 * (self.max_degree + 1)))
+                cols = np.arange(self.max_degree)[None, :]
+                for a in range(0, n, gstep):
+                    b = min(a + gstep, n)
+                    dg = deg[a:b]
+                    edges = np.fromfile(gf, dtype=np.uint32, count=int(dg.sum(dtype=np.int64)))
+                    blk = np.zeros((b - a, self.max_degree + 1), dtype=np.uint32)
+                    blk[:, 0] = dg
+                    blk[:, 1:][cols < dg[:, None]] = edges
+                    self.update_rows(np.arange(a, b, dtype=np.uint32), blk)
+            if exact_float_order:
+                check(lib.pann_index_set_exact_float_order(h, 1))
+        except Exception:
+            self.close()
+            raise
+        finally:
+            if gf is not None:
+                gf.close()
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.pann_index_destroy(self._h)

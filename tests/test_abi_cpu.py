@@ -47,6 +47,19 @@ def test_no_gpu_means_loud_failure_not_fallback():
     assert e.value.code == 3 and "no HIP device" in str(e.value)     # PANN_ERR_NO_DEVICE
 
 
+def test_streaming_loader_fails_loudly_without_a_gpu(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from parlayann_amd import DeviceIndex, PannError, io
+    io.write_bin(tmp_path / "b.bin", np.zeros((16, 8), np.uint8))
+    with pytest.raises(PannError) as e:
+        DeviceIndex.from_files(tmp_path / "b.bin", np.uint8, max_degree=4)
+    assert e.value.code == 3
+    with pytest.raises(ValueError):
+        DeviceIndex.from_files(tmp_path / "b.bin", np.uint8, max_degree=4, rows=(4, 40))     # beyond the file: checked on the host
+
+
 def test_product_never_touches_the_oracle():
     """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use oracle/"""
     bad = []

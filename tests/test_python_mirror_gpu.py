@@ -213,3 +213,45 @@ def test_parlayannpy_dropin_names():
     assert m.defaults.ALPHA == 1.2 and m.defaults.GRAPH_DEGREE == 64 and m.defaults.BEAMWIDTH == 128
     with pytest.raises(NotImplementedError):
         m.build_hnsw_float_euclidian_index("Euclidian", "a", "b", 1, 2, 3.0, 4.0)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float16, np.float32])
+def test_streamed_index_from_files_equals_in_memory_index(tmp_path, oracle, dtype):
+    """DeviceIndex.from_files (pann_index_create_empty + pann_index_upload_points + pann_index_update_rows in chunks): the whole
+    file, and one shard of it with its own graph file, give the searches of the in-memory index bit for bit"""
+    from parlayann_amd import DeviceIndex, datasets, io
+    n, d = 5000, 96
+    X = datasets.sift_like(n, d, seed=1234, dtype=dtype)
+    Q = datasets.sift_like(64, d, seed=4321, dtype=dtype)
+    G, _ = oracle.vamana_build(X, 24, 48, 1.2, seed=3)
+    io.write_bin(tmp_path / "base.bin", X); io.write_graph(tmp_path / "graph", G)
+    ref = DeviceIndex(X, G)
+    want = ref.batch_search(Q, k=10, beam=40)
+    for chunk in (1 << 12, 1 << 30):                      # many small chunks (ragged last one) / a single chunk
+        ix = DeviceIndex.from_files(tmp_path / "base.bin", dtype, graph_path=tmp_path / "graph", chunk_bytes=chunk)
+        assert (ix.n, ix.d, ix.max_degree) == (n, d, 24)
+        np.testing.assert_array_equal(ix.get_graph(), io.read_graph(tmp_path / "graph"))     # (slots past the degree are not in the file)
+        got = ix.batch_search(Q, k=10, beam=40)
+        for f in ("ids", "dists", "visited_count", "dist_cmps"):
+            np.testing.assert_array_equal(got[f], want[f])
+        ix.close()
+    ref.close()
+    # one shard: rows [1000, 3500) of the same file with the shard's own graph
+    lo, hi = 1000, 3500
+    Gs, _ = oracle.vamana_build(X[lo:hi], 16, 32, 1.2, seed=5)
+    io.write_graph(tmp_path / "graph_s", Gs)
+    sh = DeviceIndex.from_files(tmp_path / "base.bin", dtype, graph_path=tmp_path / "graph_s", rows=(lo, hi), chunk_bytes=1 << 14)
+    o = oracle.batch_search(X[lo:hi], Gs, queries=Q, k=10, beam=32)
+    g = sh.batch_search(Q, k=10, beam=32)
+    np.testing.assert_array_equal(g["ids"], o["ids"]); np.testing.assert_array_equal(g["dists"], o["dists"])
+    sh.close()
+    # no graph file: an empty graph of the requested degree, ready for a device build
+    e = DeviceIndex.from_files(tmp_path / "base.bin", dtype, max_degree=12, rows=(0, 700))
+    assert e.get_graph()[:, 0].max() == 0
+    e.vamana_build(12, 24, 1.2, seed=2)
+    Go, _ = oracle.vamana_build(X[:700], 12, 24, 1.2, seed=2)
+    np.testing.assert_array_equal(e.get_graph()[:, 0], Go[:, 0])
+    e.close()
+    with pytest.raises(ValueError):
+        DeviceIndex.from_files(tmp_path / "base.bin", dtype, graph_path=tmp_path / "graph_s")      # 2500-vertex graph, 5000 rows
+
