@@ -271,7 +271,8 @@ int pann_pivot_split(pann_index* idx, const uint32_t* ids, const uint64_t* seg_o
  * :256) and not the query's own vertex are remembered, cost one distance comparison each and join `result`
  * iff dist <= radius_2 (:280-297).  Exactly one of queries / query_ids is given (a base-point query skips
  * its own vertex, Point::same_as).  starts is nstarts ids (shared) or nq x nstarts (starts_per_query != 0);
- * 0xFFFFFFFF entries are padding.  out_ids is nq x max_results in BFS order, out_counts[i] <= max_results;
+ * 0xFFFFFFFF entries are padding.  out_ids is nq x max_results in BFS order, out_counts[i] <= max_results (entries of a
+ * row past its count are unspecified);
  * a query whose result would exceed max_results stops there and sets out_truncated[i] = 1.
  * out_dist_cmps / out_truncated may be NULL.  (The reference's first radius argument is unused, :250.) */
 int pann_range_search(pann_index* idx, const void* queries, const uint32_t* query_ids, uint64_t nq,

@@ -853,8 +853,15 @@ int pann_range_search(pann_index* idx, const void* queries, const uint32_t* quer
                                 queries ? nullptr : idx->stage[2].as<uint32_t>(), nq, idx->stage[3].as<uint32_t>(), nstarts,
                                 starts_per_query, radius_2, max_results, idx->stage[4].as<uint32_t>(),
                                 idx->stage[5].as<uint32_t>(), idx->stage[6].as<uint32_t>(), idx->stage[7].as<uint32_t>())) return rc;
-  PANN_HIP(hipMemcpyAsync(out_ids, idx->stage[4].p, nq * (uint64_t)max_results * 4, hipMemcpyDeviceToHost, st));
+  // only the columns any query filled come back (entries past a row's count are unspecified: include/pann.h)
   PANN_HIP(hipMemcpyAsync(out_counts, idx->stage[5].p, nq * 4, hipMemcpyDeviceToHost, st));
+  PANN_HIP(hipStreamSynchronize(st));
+  uint32_t widest = 0;
+  for (uint64_t i = 0; i < nq; i++) widest = std::max(widest, out_counts[i]);
+  widest = std::min(widest, max_results);
+  if (widest)
+    PANN_HIP(hipMemcpy2DAsync(out_ids, (size_t)max_results * 4, idx->stage[4].p, (size_t)max_results * 4, (size_t)widest * 4, nq,
+                              hipMemcpyDeviceToHost, st));
   if (out_dist_cmps) PANN_HIP(hipMemcpyAsync(out_dist_cmps, idx->stage[6].p, nq * 4, hipMemcpyDeviceToHost, st));
   if (out_truncated) PANN_HIP(hipMemcpyAsync(out_truncated, idx->stage[7].p, nq * 4, hipMemcpyDeviceToHost, st));
   PANN_HIP(hipStreamSynchronize(st));

@@ -280,12 +280,15 @@ class DeviceIndex:
             qid = np.ascontiguousarray(query_ids, dtype=np.uint32); nq = len(qid); qp, qs, qi = None, 0, _ptr(qid)
         if per_query and len(starts) != nq:
             raise ValueError("per-query starts must have one row per query")
-        ids = np.full((nq, max_results), 0xFFFFFFFF, np.uint32)
+        ids = np.empty((nq, max_results), np.uint32)
         cnt = np.zeros(nq, np.uint32); cmps = np.zeros(nq, np.uint32); trunc = np.zeros(nq, np.uint32)
         check(self._lib.pann_range_search(self._h, qp, qi, nq, qs, _ptr(starts), starts.shape[-1], 1 if per_query else 0,
                                           float(radius_2), max_results, _ptr(ids), _ptr(cnt), _ptr(cmps), _ptr(trunc)))
-        for i in range(nq):
-            ids[i, cnt[i]:] = 0xFFFFFFFF
+        w = int(cnt.max()) if nq else 0                      # entries past a row's count are unspecified: pad them
+        ids[:, w:] = 0xFFFFFFFF
+        if w:
+            sub = ids[:, :w]
+            sub[np.arange(w, dtype=np.uint32)[None, :] >= cnt[:, None]] = 0xFFFFFFFF
         return {"ids": ids, "counts": cnt, "dist_cmps": cmps, "truncated": trunc}
 
     def pair_distances(self, a_ids, b_ids):

@@ -53,9 +53,10 @@ def test_bf16_dense_mfma_matches_oracle(oracle, metric):
     X = datasets.sift_like(9000, 128, seed=31, dtype=bfloat16)
     Q = datasets.sift_like(70, 128, seed=32, dtype=bfloat16)
     ix = DeviceIndex(X, max_degree=8, metric=metric)
-    gi, gd = ix.bruteforce_knn(Q, 100)
-    oi, od = oracle.bruteforce_knn(X, Q, 100, metric)
-    np.testing.assert_array_equal(gi, oi); np.testing.assert_array_equal(gd, od)
+    for k in (100, 10, 16, 17):                          # register lists of 8 / 1 registers per row
+        gi, gd = ix.bruteforce_knn(Q, k)
+        oi, od = oracle.bruteforce_knn(X, Q, k, metric)
+        np.testing.assert_array_equal(gi, oi); np.testing.assert_array_equal(gd, od)
     ids = np.random.default_rng(1).choice(len(X), 700, replace=False).astype(np.uint32)
     li, ld = ix.leaf_knn(ids, 10)
     loi, lod = oracle.leaf_knn(X, ids, 10, metric)

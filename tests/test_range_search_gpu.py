@@ -119,3 +119,22 @@ def test_range_search_errors(oracle):
     with pytest.raises(ValueError):
         ix.range_search(np.array([0], np.uint32), 10.0, 8)
     ix.close()
+
+
+def test_range_search_large_balls_take_the_worst_case_table_pass(oracle):
+    """a radius that covers much of the data set: the seen sets outgrow the small per-wave tables of the first pass (more than
+    8192 ids), those queries are redone with worst-case tables; small-ball queries of the same call stay in the first pass"""
+    n = 12000
+    X, Q, G = _setup(oracle, n, 64, np.uint8, R=24)
+    ix = DeviceIndex(X, G)
+    s = ix.batch_search(Q, k=10, beam=32)
+    gt_i, gt_d = oracle.bruteforce_knn(X, Q, 2000)
+    r_big = float(np.median(gt_d[:, -1]))              # about 2000 points in the ball: ~2000 x 24 neighbours > 8192 seen ids
+    r_small = float(np.median(gt_d[:, 9]))
+    for r2, cap in ((r_big, n), (r_small, n), (r_big, 500)):
+        o = oracle.range_search(X, G, s["ids"], r2, cap, queries=Q)
+        g = ix.range_search(s["ids"], r2, cap, queries=Q)
+        _check(o, g)
+    assert oracle.range_search(X, G, s["ids"], r_big, n, queries=Q)["dist_cmps"].max() > 8192
+    ix.close()
+
