@@ -103,12 +103,12 @@ struct BSParams {
 template <bool HASH_LDS>
 __device__ __forceinline__ uint32_t hload(const uint32_t* H, uint32_t s) {
   if constexpr (HASH_LDS) return H[s];
-  else return __hip_atomic_load(H + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return __hip_atomic_load(H + s, __ATOMIC_RELAXED, PANN_PRIVATE_SCOPE);
 }
 template <bool HASH_LDS>
 __device__ __forceinline__ void hstore(uint32_t* H, uint32_t s, uint32_t v) {
   if constexpr (HASH_LDS) H[s] = v;
-  else __hip_atomic_store(H + s, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else __hip_atomic_store(H + s, v, __ATOMIC_RELAXED, PANN_PRIVATE_SCOPE);
 }
 template <bool HASH_LDS>
 __device__ __forceinline__ void hsync() {
@@ -179,7 +179,7 @@ __device__ __forceinline__ void filter_undo(uint32_t* H, const FilterUndo& u, ui
   if (u.wrote) {
     const uint32_t hm = (1u << hb) - 1u;
     if constexpr (HASH_LDS) H[u.s] = u.old;
-    else if (hb != 3 && (u.s & hm) == hm) __hip_atomic_store(H + (u.s >> hb), u.old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (hb != 3 && (u.s & hm) == hm) __hip_atomic_store(H + (u.s >> hb), u.old, __ATOMIC_RELAXED, PANN_PRIVATE_SCOPE);
     else lds_part_store(Lp, split_lds_index(u.s, hb), u.old);
   }
   PANN_WSYNC();
@@ -202,7 +202,7 @@ __device__ __forceinline__ bool filter_update(uint32_t* H, uint32_t hmask, bool 
   } else {
     __builtin_amdgcn_s_waitcnt(0);                       // the previous call's table stores have been acknowledged
     old = 0u;
-    if (active) old = in_hbm ? __hip_atomic_load(H + (s >> hb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : lds_part_load(Lp, split_lds_index(s, hb));
+    if (active) old = in_hbm ? __hip_atomic_load(H + (s >> hb), __ATOMIC_RELAXED, PANN_PRIVATE_SCOPE) : lds_part_load(Lp, split_lds_index(s, hb));
     const uint32_t t = s & 1023u;
     if (active) T[t] = (uint8_t)lane;
     PANN_WSYNC();
@@ -231,7 +231,7 @@ __device__ __forceinline__ bool filter_update(uint32_t* H, uint32_t hmask, bool 
     PANN_WSYNC();
   } else {
     if (active && last) {
-      if (in_hbm) __hip_atomic_store(H + (s >> hb), a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (in_hbm) __hip_atomic_store(H + (s >> hb), a, __ATOMIC_RELAXED, PANN_PRIVATE_SCOPE);
       else lds_part_store(Lp, split_lds_index(s, hb), a);
     }
     PANN_WSYNC();                                     // T (and the LDS part) may be touched by the next call
@@ -456,7 +456,7 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES) beam_search_kernel(B
               if (pos < beam) {
                 uint32_t flag = 0u;   // re-entry of an already visited vertex? (only while not full)
                 for (uint32_t t = 0; t < ndrop; t++)
-                  flag |= (__hip_atomic_load(DL + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key) ? 2u : 0u;
+                  flag |= (__hip_atomic_load(DL + t, __ATOMIC_RELAXED, PANN_PRIVATE_SCOPE) == key) ? 2u : 0u;
                 NF[pos] = key; NFv[pos] = (uint8_t)flag;
               }
             }
@@ -704,7 +704,7 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES_B64) beam_search_b64_
         if (clive && cpos < beam) {
           uint32_t flag = 0u;   // re-entry of an already visited vertex (only while the frontier is not full)
           for (uint32_t t = 0; t < ndrop; t++)
-            flag |= (__hip_atomic_load(DL + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ckey) ? 2u : 0u;
+            flag |= (__hip_atomic_load(DL + t, __ATOMIC_RELAXED, PANN_PRIVATE_SCOPE) == ckey) ? 2u : 0u;
           S[cpos] = ckey; Sv[cpos] = (uint8_t)flag;
         }
         if (fl && fpos < beam) { S[fpos] = fkey; Sv[fpos] = (uint8_t)fflag; }
@@ -1002,7 +1002,7 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
         if (clive && cpos < beam) {
           uint32_t flag = 0u;
           for (uint32_t t = 0; t < ndrop; t++)
-            flag |= (__hip_atomic_load(DL + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ckey) ? 2u : 0u;
+            flag |= (__hip_atomic_load(DL + t, __ATOMIC_RELAXED, PANN_PRIVATE_SCOPE) == ckey) ? 2u : 0u;
           S[cpos] = ckey; Sv[cpos] = (uint8_t)flag;
         }
 #pragma unroll

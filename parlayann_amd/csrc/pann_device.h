@@ -514,6 +514,15 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
   return ((uint64_t)hi << 32) | lo;
 }
 
+// Memory scope for atomics / coherent loads and stores on data that ONE workgroup owns for the whole kernel (a wave's filter
+// table, dropped list, candidate list, seen set, result row).  Workgroup scope is what the data needs: the access bypasses the
+// CU's L1 (sc0: a slot written a moment ago must not be read back stale) and nothing has to be coherent across XCDs.  Measured
+// against agent scope (sc1) on the Vamana build and the range search: the same within noise, so this is about stating the
+// requirement, not about speed.  (Build with -DPANN_PRIVATE_SCOPE=__HIP_MEMORY_SCOPE_AGENT for the A/B.)
+#ifndef PANN_PRIVATE_SCOPE
+#define PANN_PRIVATE_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#endif
+
 // Block-wide sync for kernels whose workgroup is ONE wavefront: LDS instructions of a wave execute in order, so all
 // that is needed between a lane's ds_write and another lane's ds_read is that the compiler keeps the order.
 // Unlike __syncthreads() this does not drain outstanding global loads / stores (s_waitcnt vmcnt(0)), so memory

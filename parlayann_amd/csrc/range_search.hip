@@ -39,7 +39,7 @@ struct RSArgs {
 };
 
 __device__ __forceinline__ unsigned long long rs_load(const unsigned long long* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, PANN_PRIVATE_SCOPE);
 }
 
 // is `id` in this query's set?  If not, *slot / *stale are where the probe ended: the first slot of the chain that does not
@@ -62,7 +62,7 @@ __device__ __forceinline__ void rs_insert(unsigned long long* T, uint64_t mask, 
   const unsigned long long mine = (tag << 32) | id;
   for (;;) {
     if ((e >> 32) != tag) {
-      if (__hip_atomic_compare_exchange_strong(T + h, &e, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      if (__hip_atomic_compare_exchange_strong(T + h, &e, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, PANN_PRIVATE_SCOPE))
         return;
       if ((e >> 32) != tag) continue;      // the slot changed under us but is still free: try it again
     }
@@ -126,14 +126,14 @@ __global__ void __launch_bounds__(PANN_WAVE) range_search_kernel(RSArgs A) {
       const bool in = lane < (int)m && Dl[lane] <= A.radius_2;
       const uint64_t im = __ballot(in);
       const uint32_t pos = count + lanes_below(im, lane);
-      if (in && pos < A.cap) { __hip_atomic_store(res + pos, Pl[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); Rq[pos % RS_RING] = Pl[lane]; }
+      if (in && pos < A.cap) { __hip_atomic_store(res + pos, Pl[lane], __ATOMIC_RELAXED, PANN_PRIVATE_SCOPE); Rq[pos % RS_RING] = Pl[lane]; }
       const uint32_t add = (uint32_t)__popcll(im);
       if (count + add > A.cap) trunc = true;
       count = min(count + add, A.cap);
     };
     auto result_at = [&](uint32_t pos) -> uint32_t {        // pos < count (wave-uniform)
       if (pos + RS_RING >= count) return Rq[pos % RS_RING];
-      return __hip_atomic_load(res + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return __hip_atomic_load(res + pos, __ATOMIC_RELAXED, PANN_PRIVATE_SCOPE);
     };
 
     // ---- starts (:271-277) ----
@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(PANN_WAVE) range_search_kernel(RSArgs A) {
       const bool in = pass && !shadowed;
       const uint64_t im = __ballot(in);
       const uint32_t pos = count + lanes_below(im, lane);
-      if (in && pos < A.cap) { __hip_atomic_store(res + pos, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); Rq[pos % RS_RING] = id; }
+      if (in && pos < A.cap) { __hip_atomic_store(res + pos, id, __ATOMIC_RELAXED, PANN_PRIVATE_SCOPE); Rq[pos % RS_RING] = id; }
       const uint32_t add = (uint32_t)__popcll(im);
       if (A.ovf_list && ins + add > ins_limit) { overflow = true; break; }
       if (in) {            // (the passing start sits on another lane than the probe did: probe again from its home slot)

@@ -114,10 +114,10 @@ struct GreedyArgs {
 };
 
 __device__ __forceinline__ uint64_t ld_key(const uint64_t* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, PANN_PRIVATE_SCOPE);
 }
 __device__ __forceinline__ void st_key(uint64_t* p, uint64_t v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, PANN_PRIVATE_SCOPE);
 }
 
 // greedy alpha-prune over the sorted, de-duplicated candidate list (:90-116).  One wave per owner.  The list
