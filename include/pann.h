@@ -227,6 +227,12 @@ int pann_vamana_insert_batch(pann_index* idx, const uint32_t* batch_ids, uint64_
 int pann_vamana_build(pann_index* idx, uint32_t R, uint32_t L, double alpha, int num_passes,
                       uint64_t seed, int sort_neighbors, pann_build_stats* stats);
 
+/* build_index with BP.single_batch = degree != 0 (vamana/index.h:156-170,236-240): every vertex first gets `degree` random
+ * out-edges, then each pass inserts ALL points as one batch.  The reference draws the edges from parlay::random_generator over
+ * [0, n] (n itself is out of range there); this build draws splitmix64(seed, i * degree + j) mod n. */
+int pann_vamana_build_single_batch(pann_index* idx, uint32_t R, uint32_t L, double alpha, int num_passes, uint32_t degree,
+                                   uint64_t seed, int sort_neighbors, pann_build_stats* stats);
+
 /* The two phases of one batch on DEVICE pointers -- the seam of the multi-GPU build (SURVEY.md section 8e row 3;
  * parlayann_amd/distributed.py): with the points and the graph replicated, every rank runs phase A on its slice of the
  * batch, the slices' rows are all-gathered (ONE collective per batch, m x R x 4 bytes), and every rank applies the rows of

@@ -523,6 +523,46 @@ int pann_oracle_vamana_insert_batch(const void* points, uint64_t n, uint32_t d, 
 }
 
 // vamana/index.h:150-186 build_index + the batch schedule of :200-234.
+// build_index with BP.single_batch = degree (vamana/index.h:156-170,236-240): `degree` random out-edges per vertex, then every
+// pass inserts all points as ONE batch.  The start edges come from this build's own generator (the reference's
+// parlay::random_generator is not reproducible offline): edge j of vertex i = splitmix64(seed + golden * (i*degree + j + 1)) mod n.
+int pann_oracle_vamana_build_single_batch(const void* points, uint64_t n, uint32_t d, int dtype, uint64_t stride,
+                                          int metric, uint32_t* graph, uint32_t maxdeg, uint32_t R, uint32_t L,
+                                          double alpha, int num_passes, uint32_t degree, uint64_t seed, int sort_neighbors,
+                                          uint64_t* stats6, int nthreads) {
+  if (degree == 0 || degree > maxdeg) return 1;
+  std::vector<uint32_t> perm(n);
+  pann_oracle_permutation(n, seed, perm.data());
+  for (uint64_t i = 0; i < n; i++) {
+    uint32_t* row = graph + i * (uint64_t)(maxdeg + 1);
+    row[0] = degree;
+    for (uint32_t j = 0; j < degree; j++) {
+      uint64_t z = seed + 0x9e3779b97f4a7c15ull * (i * degree + j + 1);
+      z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+      z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+      z ^= z >> 31;
+      row[1 + j] = (uint32_t)(z % n);
+    }
+  }
+  for (int pass = 0; pass < num_passes; pass++) {
+    const double a = (pass == num_passes - 1) ? alpha : 1.0;  // :173-178
+    int rc = pann_oracle_vamana_insert_batch(points, n, d, dtype, stride, metric, graph, maxdeg, perm.data(), n, 0, R, L, a,
+                                             stats6, nthreads);      // floor = 0, ceiling = m (:236-240)
+    if (rc) return rc;
+  }
+  if (sort_neighbors) {  // :180-185; ties broken by id
+    Dataset D{(const uint8_t*)points, n, d, dtype, stride, metric, graph, maxdeg};
+    parallel_for(0, n, nthreads, [&](size_t i) {
+      uint32_t* row = graph + i * (uint64_t)(maxdeg + 1);
+      std::vector<IdDist> v;
+      for (uint32_t j = 0; j < row[0]; j++) v.push_back(IdDist{row[1 + j], D.dist_ids((uint32_t)i, row[1 + j])});
+      std::sort(v.begin(), v.end(), less_id_dist);
+      for (uint32_t j = 0; j < row[0]; j++) row[1 + j] = v[j].id;
+    });
+  }
+  return 0;
+}
+
 int pann_oracle_vamana_build(const void* points, uint64_t n, uint32_t d, int dtype, uint64_t stride,
                              int metric, uint32_t* graph, uint32_t maxdeg, uint32_t R, uint32_t L,
                              double alpha, int num_passes, uint64_t seed, int sort_neighbors,

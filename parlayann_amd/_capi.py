@@ -87,6 +87,8 @@ SIGNATURES = {
                                           C.c_double, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
     "pann_vamana_insert_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                            C.c_double, C.POINTER(BuildStats)]),
+    "pann_vamana_build_single_batch": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_double, C.c_int, C.c_uint32, C.c_uint64,
+                                                 C.c_int, C.c_void_p]),
     "pann_vamana_build": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_double, C.c_int, C.c_uint64, C.c_int,
                                     C.POINTER(BuildStats)]),
     "pann_vamana_search_prune_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,

@@ -574,6 +574,54 @@ uint64_t pann_vamana_batch_schedule(uint64_t n, uint64_t m, uint64_t* bounds, ui
   return nb;
 }
 
+namespace {
+// vamana/index.h:156-170 with this build's own generator: edge j of vertex i = splitmix64(seed + golden * (i*degree + j + 1)) mod n
+__global__ void random_edges_kernel(uint32_t* graph, uint32_t gstride, uint64_t n, uint32_t degree, uint64_t seed) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * gstride) return;
+  const uint64_t i = t / gstride, j = t % gstride;
+  uint32_t v = SENTINEL;
+  if (j < degree) {
+    uint64_t z = seed + 0x9e3779b97f4a7c15ull * (i * degree + j + 1);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    z ^= z >> 31;
+    v = (uint32_t)(z % n);
+  }
+  graph[t] = v;
+}
+}  // namespace
+
+int pann_vamana_build_single_batch(pann_index* idx, uint32_t R, uint32_t L, double alpha, int num_passes, uint32_t degree,
+                                   uint64_t seed, int sort_neighbors, pann_build_stats* stats) {
+  if (int rc = check_idx(idx, "pann_vamana_build_single_batch")) return rc;
+  if (L == 0 || L > 65536 || num_passes < 1) { set_error("pann_vamana_build_single_batch: bad L / num_passes"); return PANN_ERR_BAD_ARG; }
+  if (degree == 0 || degree > idx->ix.max_deg) { set_error("pann_vamana_build_single_batch: degree must be in [1, max_deg]"); return PANN_ERR_BAD_ARG; }
+  DeviceGuard g(idx->device);
+  const uint64_t n = idx->ix.n;
+  if (n >= 0xFFFFFFFFull / 2) { set_error("pann_vamana_build_single_batch: n too large for one batch"); return PANN_ERR_BAD_ARG; }
+  std::vector<uint32_t> perm;
+  build_permutation(n, seed, perm);
+  if (int rc = idx->stage[2].ensure(n * 4)) return rc;
+  PANN_HIP(hipMemcpyAsync(idx->stage[2].p, perm.data(), n * 4, hipMemcpyHostToDevice, idx->stream));
+  {
+    const uint64_t tot = n * idx->ix.gstride;
+    hipLaunchKernelGGL(random_edges_kernel, dim3((uint32_t)((tot + 255) / 256)), dim3(256), 0, idx->stream, idx->ix.graph,
+                       idx->ix.gstride, n, degree, seed);
+    PANN_HIP(hipGetLastError());
+  }
+  PANN_HIP(hipStreamSynchronize(idx->stream));
+  if (idx->vcap < default_vcap(L)) idx->vcap = default_vcap(L);
+  for (int pass = 0; pass < num_passes; pass++) {
+    const double a = (pass == num_passes - 1) ? alpha : 1.0;   // :173-178
+    if (int rc = insert_batch_dev(idx->ix, idx->ws2, idx->ws3, idx->ws, idx->ws4, idx->stream, idx->stage[2].as<uint32_t>(),
+                                  (uint32_t)n, 0u, R, L, a, &idx->vcap, stats))      // floor = 0, ceiling = m (:236-240)
+      return rc;
+  }
+  if (sort_neighbors) return sort_neighbors_dev(idx->ix, idx->stream);
+  return PANN_OK;
+}
+
 int pann_vamana_build(pann_index* idx, uint32_t R, uint32_t L, double alpha, int num_passes, uint64_t seed,
                       int sort_neighbors, pann_build_stats* stats) {
   if (int rc = check_idx(idx, "pann_vamana_build")) return rc;

@@ -6,7 +6,7 @@
 // Flags as upstream: -base_path -query_path -gt_path -graph_path -graph_outfile -res_path -data_type {uint8,int8,float}
 //   -dist_func {Euclidian,mips} -k -Q -R -L -alpha -num_passes -two_pass -mst_deg -num_clusters -cluster_size -delta
 //   -quantize_bits {0,8} -quantize_mode {0,1} -verbose -normalize -self -range -radius -radius_2 -rerank_factor
-//   (-single_batch, -quantize_bits 16 and -quantize_mode 2..5 are rejected: out of scope).
+//   (-quantize_bits 16 and -quantize_mode 2..5 are rejected: out of scope).
 // Added here: -device <ordinal>, -seed <s>, -use_existing (self range search seeded with out-neighbours),
 //   -host_tree (HCNNG cross-check path).
 #include <chrono>

@@ -58,16 +58,18 @@ struct knn_index {
     std::cout << "Building graph..." << std::endl;
     set_start();
     check_ranges(Points, QPoints);
-    if (BP.single_batch != 0) {
-      std::cout << "Error: -single_batch (random start edges from parlay::random_generator, :153-170) is not mirrored" << std::endl;
-      abort();
-    }
+    if (BP.single_batch != 0)
+      std::cout << "Using single batch per round with " << BP.single_batch << " random start edges" << std::endl;      // :158
     std::cout << "number of passes = " << BP.num_passes << std::endl;
     last = pann_build_stats{};
     attach_stats(BuildStats, Points.size());
     // G holds the starting graph (empty after Graph(maxDeg, n); a loaded graph is extended, as upstream)
     auto L = device_mirror(G, Points);
-    pann_check(pann_vamana_build(L.h(), (uint32_t)BP.R, (uint32_t)BP.L, BP.alpha, BP.num_passes, seed, sort_neighbors ? 1 : 0, &last));
+    if (BP.single_batch != 0)      // :156-170,236-240 (this build's own generator for the start edges: DESIGN.md section 6)
+      pann_check(pann_vamana_build_single_batch(L.h(), (uint32_t)BP.R, (uint32_t)BP.L, BP.alpha, BP.num_passes,
+                                                (uint32_t)BP.single_batch, seed, sort_neighbors ? 1 : 0, &last));
+    else
+      pann_check(pann_vamana_build(L.h(), (uint32_t)BP.R, (uint32_t)BP.L, BP.alpha, BP.num_passes, seed, sort_neighbors ? 1 : 0, &last));
     MirrorCache::download_graph(L, G);
     detach_stats(BuildStats);
     std::cout << "beam search time: " << last.t_search_s << std::endl;        // the reference's phase timers (:313-315)

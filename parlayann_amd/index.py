@@ -236,10 +236,16 @@ class DeviceIndex:
         check(self._lib.pann_vamana_insert_batch(self._h, _ptr(b), len(b), start, R, L, float(alpha), C.byref(st)))
         return st
 
-    def vamana_build(self, R, L, alpha, num_passes=1, seed=1, sort_neighbors=True):
+    def vamana_build(self, R, L, alpha, num_passes=1, seed=1, sort_neighbors=True, single_batch=0):
+        """build_index (vamana/index.h:150-186).  single_batch = degree != 0: BuildParams::single_batch -- `degree` random
+        start edges per vertex, then every pass is one batch of all points (:156-170,236-240)."""
         st = BuildStats()
-        check(self._lib.pann_vamana_build(self._h, R, L, float(alpha), num_passes, seed, 1 if sort_neighbors else 0,
-                                          C.byref(st)))
+        if single_batch:
+            check(self._lib.pann_vamana_build_single_batch(self._h, R, L, float(alpha), num_passes, int(single_batch), seed,
+                                                           1 if sort_neighbors else 0, C.byref(st)))
+        else:
+            check(self._lib.pann_vamana_build(self._h, R, L, float(alpha), num_passes, seed, 1 if sort_neighbors else 0,
+                                              C.byref(st)))
         return st
 
     # ---- the two phases of a batch on device pointers (multi-GPU build, parlayann_amd/distributed.py) ----

@@ -163,13 +163,21 @@ class Oracle:
         assert rc == 0
 
     def vamana_build(self, points, R, L, alpha, num_passes=1, seed=1, sort_neighbors=True, metric="l2",
-                     max_degree=None, threads=None, point_stats=None):
+                     max_degree=None, threads=None, point_stats=None, single_batch=0):
         """point_stats: optional (visited[n], dists[n]) uint32 arrays, accumulated like the reference's BuildStats"""
         points = np.ascontiguousarray(points)
         n, d = points.shape
         maxdeg = R if max_degree is None else max_degree
         graph = np.zeros((n, maxdeg + 1), np.uint32)
         stats = np.zeros(6, np.uint64)
+        if single_batch:
+            rc = self.lib.pann_oracle_vamana_build_single_batch(
+                _p(points), C.c_uint64(n), C.c_uint32(d), C.c_int(DT[points.dtype]), C.c_uint64(points.strides[0]),
+                C.c_int(_m(metric)), _p(graph), C.c_uint32(maxdeg), C.c_uint32(R), C.c_uint32(L), C.c_double(alpha),
+                C.c_int(num_passes), C.c_uint32(single_batch), C.c_uint64(seed), C.c_int(1 if sort_neighbors else 0), _p(stats),
+                C.c_int(threads or self.threads))
+            assert rc == 0
+            return graph, stats
         if point_stats is not None:
             self.lib.pann_oracle_set_build_point_stats(_p(point_stats[0]), _p(point_stats[1]))
         rc = self.lib.pann_oracle_vamana_build(

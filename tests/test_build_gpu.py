@@ -91,6 +91,25 @@ def test_full_build_identical_graph(oracle, dtype, metric, d, n, R, L, passes):
     ix.close()
 
 
+@pytest.mark.parametrize("dtype,metric,d,n,R,L,deg,passes", [
+    (np.uint8, "l2", 64, 6000, 24, 48, 4, 2), (np.float16, "l2", 128, 3000, 32, 64, 8, 1), (np.int8, "mips", 100, 4000, 16, 40, 16, 2),
+])
+def test_single_batch_build_identical_graph(oracle, dtype, metric, d, n, R, L, deg, passes):
+    """BuildParams::single_batch (vamana/index.h:156-170,236-240): `deg` random start edges per vertex, every pass ONE batch of all
+    points -- graph and counters equal the oracle's (same generator for the start edges)"""
+    X = datasets.sift_like(n, d, seed=1234, dtype=np.float32)
+    X = (X - 128).clip(-127, 127).astype(np.int8) if dtype == np.int8 else X.astype(dtype)
+    alpha = 1.2 if metric == "l2" else 1.0
+    Go, so = oracle.vamana_build(X, R, L, alpha, num_passes=passes, seed=7, metric=metric, single_batch=deg)
+    ix = DeviceIndex(X, max_degree=R, metric=metric)
+    sg = ix.vamana_build(R, L, alpha, num_passes=passes, seed=7, single_batch=deg)
+    np.testing.assert_array_equal(_norm(Go), _norm(ix.get_graph()))
+    assert int(so[0]) == sg.search_dist_cmps and int(so[1]) == sg.prune_dist_cmps
+    with pytest.raises(Exception):
+        ix.vamana_build(R, L, alpha, single_batch=R + 1)          # more start edges than a row holds
+    ix.close()
+
+
 def test_build_with_batches_above_2048_inserts(oracle):
     """n = 110 000 -> insert batches of 2 200 (max_batch = 0.02 n, vamana/index.h:206-207): with L in 65..128 the
     builder's searches run on the persistent beam-128 kernel with the split LDS/HBM filter; the graph must still be

@@ -88,6 +88,20 @@ def test_vamana_cli_builds_the_same_graph_and_reports_recall(exe, files, oracle)
     assert re.findall(r"recall=([0-9.]+)", out2)[0] == re.findall(r"recall=([0-9.]+)", out)[0]
 
 
+def test_vamana_cli_single_batch(exe, files, oracle):
+    """-single_batch 6 (BuildParams::single_batch, vamana/index.h:156-170,236-240): random start edges, one batch per pass"""
+    d, X, Q, gt, gd = files
+    out = _run(exe, "-base_path", d / "base.bin", "-query_path", d / "query.bin", "-gt_path", d / "gt.ibin",
+               "-graph_outfile", d / "sb.graph", "-data_type", "uint8", "-dist_func", "Euclidian", "-R", 32, "-L", 64,
+               "-alpha", 1.2, "-num_passes", 2, "-single_batch", 6, "-k", 10, "-Q", 64, "-seed", 5)
+    assert "Using single batch per round with 6 random start edges" in out
+    G = io.read_graph(d / "sb.graph")
+    Go, _ = oracle.vamana_build(X, 32, 64, 1.2, num_passes=2, seed=5, single_batch=6)
+    cols = np.arange(32)[None, :]
+    np.testing.assert_array_equal(G[:, 0], Go[:, 0])
+    np.testing.assert_array_equal(np.where(cols < G[:, :1], G[:, 1:], 0), np.where(cols < Go[:, :1], Go[:, 1:], 0))
+
+
 def test_hcnng_cli_graph_quality(exe, files):
     d, X, Q, gt, gd = files
     out = _run(exe, "-base_path", d / "base.bin", "-query_path", d / "query.bin", "-gt_path", d / "gt.ibin",
