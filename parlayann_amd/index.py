@@ -236,10 +236,17 @@ class DeviceIndex:
         check(self._lib.pann_vamana_insert_batch(self._h, _ptr(b), len(b), start, R, L, float(alpha), C.byref(st)))
         return st
 
-    def vamana_build(self, R, L, alpha, num_passes=1, seed=1, sort_neighbors=True, single_batch=0):
+    def vamana_build(self, R, L, alpha, num_passes=1, seed=1, sort_neighbors=True, single_batch=0, point_stats=None):
         """build_index (vamana/index.h:150-186).  single_batch = degree != 0: BuildParams::single_batch -- `degree` random
-        start edges per vertex, then every pass is one batch of all points (:156-170,236-240)."""
+        start edges per vertex, then every pass is one batch of all points (:156-170,236-240).
+        point_stats = (visited[n], dist_cmps[n]) uint32 arrays: accumulated per point like the reference's BuildStats (stats.h:63-73)."""
         st = BuildStats()
+        if point_stats is not None:
+            vis, dc = point_stats
+            if not all(a.dtype == np.uint32 and a.flags.c_contiguous and a.shape == (self.n,) for a in (vis, dc)):
+                raise ValueError("point_stats must be two C-contiguous uint32 arrays of n entries")
+            st.per_point_visited = vis.ctypes.data_as(C.c_void_p)
+            st.per_point_dist_cmps = dc.ctypes.data_as(C.c_void_p)
         if single_batch:
             check(self._lib.pann_vamana_build_single_batch(self._h, R, L, float(alpha), num_passes, int(single_batch), seed,
                                                            1 if sort_neighbors else 0, C.byref(st)))

@@ -94,3 +94,53 @@ def test_device_reproduces_golden_v2():
     np.testing.assert_array_equal(fr["ids"], gold["fl_ids"]); np.testing.assert_array_equal(fr["dists"].view(np.uint32), gold["fl_dists"].view(np.uint32))
     np.testing.assert_array_equal(fr["dist_cmps"], gold["fl_cmps"]); np.testing.assert_array_equal(fr["visited_count"], gold["fl_vis"])
     fx.close()
+
+
+G3_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_v3.npz")
+
+
+def test_oracle_reproduces_golden_v3(oracle):
+    """bfloat16 points, the single-batch build, exact kNN at k = 100 / 10, per-point build statistics: the oracle regenerates
+    tests/golden/oracle_v3.npz"""
+    from golden.make_golden_v3 import compute
+    gold = np.load(G3_PATH)
+    now = compute(oracle)
+    assert set(now) == set(gold.files)
+    for k in gold.files:
+        np.testing.assert_array_equal(gold[k], now[k], err_msg=k)
+
+
+@pytest.mark.gpu
+def test_device_reproduces_golden_v3():
+    from parlayann_amd import DeviceIndex
+    from parlayann_amd.bf16 import bfloat16
+    gold = np.load(G3_PATH)
+    X = gold["sb_X"]; cols = np.arange(16)[None, :]
+
+    def norm(G):
+        return np.concatenate([G[:, :1], np.where(cols < G[:, :1], G[:, 1:], 0)], 1)
+    ix = DeviceIndex(X, max_degree=16)
+    st = ix.vamana_build(16, 32, 1.2, num_passes=2, seed=5, single_batch=4)
+    np.testing.assert_array_equal(norm(ix.get_graph()), norm(gold["sb_G"]))
+    assert (st.search_dist_cmps, st.prune_dist_cmps) == tuple(int(v) for v in gold["sb_cmps"])
+    Q = gold["gt_Q"]
+    for k in (100, 10):                                   # register lists of 8 / 1 registers per row, v_dot4 tile
+        gi, gd = ix.bruteforce_knn(Q, k)
+        np.testing.assert_array_equal(gi, gold[f"gt_u8_ids{k}"]); np.testing.assert_array_equal(gd, gold[f"gt_u8_d{k}"])
+    ix.close()
+    ih = DeviceIndex(X.astype(np.float16), max_degree=8, metric="mips")        # the MFMA ground-truth kernel
+    gi, gd = ih.bruteforce_knn(Q.astype(np.float16), 100)
+    np.testing.assert_array_equal(gi, gold["gt_f16_mips_ids"]); np.testing.assert_array_equal(gd, gold["gt_f16_mips_d"])
+    ih.close()
+    ib = DeviceIndex(gold["bf_X"].view(bfloat16), gold["bf_G"])
+    rb = ib.batch_search(gold["bf_Q"].view(bfloat16), k=10, beam=32, out_k=12)
+    np.testing.assert_array_equal(rb["ids"], gold["bf_ids"]); np.testing.assert_array_equal(rb["dists"], gold["bf_dists"])
+    np.testing.assert_array_equal(rb["dist_cmps"], gold["bf_cmps"])
+    ib.close()
+    vis = np.zeros(len(X), np.uint32); dc = np.zeros(len(X), np.uint32)
+    ip = DeviceIndex(X, max_degree=16)
+    ip.vamana_build(16, 32, 1.2, num_passes=1, seed=9, point_stats=(vis, dc))
+    np.testing.assert_array_equal(norm(ip.get_graph()), norm(gold["ps_G"]))
+    np.testing.assert_array_equal(vis, gold["ps_visited"]); np.testing.assert_array_equal(dc, gold["ps_dists"])
+    ip.close()
+
