@@ -44,16 +44,21 @@ __device__ __forceinline__ unsigned long long rs_load(const unsigned long long* 
 
 // is `id` in this query's set?  If not, *slot / *stale are where the probe ended: the first slot of the chain that does not
 // belong to this query, and the (stale) entry found there -- rs_insert starts from them without reading the slot again.
-__device__ __forceinline__ bool rs_contains(const unsigned long long* T, uint64_t mask, uint64_t tag, uint32_t id,
-                                            uint64_t* slot, unsigned long long* stale) {
-  uint64_t h = hash64_2(id) & mask;
+// (h, e): the id's home slot and the entry already read from it -- the caller may have requested that read earlier
+__device__ __forceinline__ bool rs_contains_from(const unsigned long long* T, uint64_t mask, uint64_t tag, uint32_t id, uint64_t h,
+                                                 unsigned long long e, uint64_t* slot, unsigned long long* stale) {
   const unsigned long long want = (tag << 32) | id;
   for (;;) {
-    const unsigned long long e = rs_load(T + h);
     if (e == want) return true;
     if ((e >> 32) != tag) { *slot = h; *stale = e; return false; }
     h = (h + 1) & mask;
+    e = rs_load(T + h);
   }
+}
+__device__ __forceinline__ bool rs_contains(const unsigned long long* T, uint64_t mask, uint64_t tag, uint32_t id,
+                                            uint64_t* slot, unsigned long long* stale) {
+  const uint64_t h = hash64_2(id) & mask;
+  return rs_contains_from(T, mask, tag, id, h, rs_load(T + h), slot, stale);
 }
 
 // insert `id` (known to be absent; concurrent lanes of the wave insert distinct ids), starting at the slot rs_contains ended on
@@ -71,15 +76,30 @@ __device__ __forceinline__ void rs_insert(unsigned long long* T, uint64_t mask, 
   }
 }
 
-// true on lanes whose (valid) id also sits on a lower valid lane
-__device__ __forceinline__ bool rs_dup_of_lower_lane(uint32_t id, bool valid, int lane) {
+// true on lanes whose (valid) id also sits on a lower valid lane.  Every valid lane writes its number into a byte table slot
+// chosen by its id; a lane that reads back another lane's number shares the slot with somebody -- only those slot groups
+// (about two per 64 ids at 1024 slots) are walked member by member.  W: 1024 bytes of LDS, contents irrelevant on entry.
+__device__ __forceinline__ bool rs_dup_of_lower_lane(uint32_t id, bool valid, int lane, uint8_t* W) {
+  const uint32_t s = (id * 0x9E3779B1u) >> 22;              // 10 bits
+  if (valid) W[s] = (uint8_t)lane;
+  wave_lds_sync();
+  const uint32_t w = valid ? (uint32_t)W[s] : (uint32_t)lane;
+  uint64_t losers = __ballot(valid && w != (uint32_t)lane);
   bool dup = false;
-  const uint64_t vm = __ballot(valid);
-  for (int l = 0; l < PANN_WAVE - 1; l++) {
-    if (!((vm >> l) & 1)) continue;                       // wave-uniform
-    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)id, l);
-    dup |= valid && lane > l && o == id;
+  while (losers) {
+    const int L = __ffsll((unsigned long long)losers) - 1;
+    const uint32_t sL = (uint32_t)__builtin_amdgcn_readlane((int)s, L);
+    uint64_t grp = __ballot(valid && s == sL);              // every lane of that slot, winners included
+    losers &= ~grp;
+    const bool mine = valid && s == sL;
+    while (grp) {                                           // ascending: a member is a duplicate of any EARLIER member with its id
+      const int M = __ffsll((unsigned long long)grp) - 1;
+      grp &= grp - 1;
+      const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)id, M);
+      dup |= mine && lane > M && o == id;
+    }
   }
+  wave_lds_sync();                                          // W may be rewritten by the next call
   return dup;
 }
 
@@ -94,6 +114,7 @@ __global__ void __launch_bounds__(PANN_WAVE) range_search_kernel(RSArgs A) {
   // back from HBM would put one more memory round trip on the per-vertex chain (entries older than the ring come from HBM)
   constexpr uint32_t RS_RING = 512;
   __shared__ uint32_t Rq[RS_RING];
+  __shared__ uint8_t Wd[1024];                              // scratch of rs_dup_of_lower_lane
   extern __shared__ __align__(16) uint8_t smem[];
   uint4* qlds = reinterpret_cast<uint4*>(smem);
   unsigned long long* T = A.table + (uint64_t)blockIdx.x * A.hsize;
@@ -185,13 +206,19 @@ __global__ void __launch_bounds__(PANN_WAVE) range_search_kernel(RSArgs A) {
     // ---- BFS (:280-297) ----
     // The first 64 neighbours of the vertex after the current one are requested one iteration ahead whenever that vertex is
     // already in the result (nearly always: the queue is longer than one), which takes the row fetch off the per-vertex chain.
+    // ... and the first probe of those neighbours is requested while the current vertex's candidate rows are in flight (the
+    // table does not change between that request and its use: inserts happen before the candidates are scored), which leaves two
+    // dependent round trips per vertex -- max(probe, candidate rows) and the compare-and-swap -- instead of three.
     uint32_t position = 0;
     uint32_t pre_row = SENTINEL; bool pre_ok = false;
+    bool pp_ok = false; uint64_t pp_h = 0; unsigned long long pp_e = 0;
     while (position < count && !trunc && !overflow) {
       const uint32_t next = result_at(position);
       position++;
       const uint32_t* row = A.graph + (uint64_t)next * A.gstride;
       const uint32_t first = pre_ok ? pre_row : ((uint32_t)lane < A.gstride ? row[lane] : SENTINEL);
+      const bool have_pp = pp_ok; const uint64_t my_h = pp_h; const unsigned long long my_e = pp_e;
+      pp_ok = false;
       pre_ok = position < count;                            // the next vertex is known now (entries below count are final)
       if (pre_ok) {
         const uint32_t nn = result_at(position);
@@ -202,8 +229,11 @@ __global__ void __launch_bounds__(PANN_WAVE) range_search_kernel(RSArgs A) {
         const bool valid = v != SENTINEL;
         if (__ballot(valid) == 0) break;                    // neighbours are packed at the front of the row
         uint64_t slot = 0; unsigned long long stale = 0;
-        bool unseen = valid && v != self && !rs_contains(T, mask, tag, v, &slot, &stale);
-        unseen = unseen && !rs_dup_of_lower_lane(v, unseen, lane);
+        bool unseen = valid && v != self;
+        if (unseen) unseen = (j0 == 0 && have_pp) ? !rs_contains_from(T, mask, tag, v, my_h, my_e, &slot, &stale)
+                                                  : !rs_contains(T, mask, tag, v, &slot, &stale);
+        const bool dup = rs_dup_of_lower_lane(v, unseen, lane, Wd);       // (all lanes call it: it synchronises on LDS)
+        unseen = unseen && !dup;
         const uint64_t um = __ballot(unseen);
         const uint32_t m = (uint32_t)__popcll(um);
         if (m == 0) continue;
@@ -212,6 +242,11 @@ __global__ void __launch_bounds__(PANN_WAVE) range_search_kernel(RSArgs A) {
         ins += m;
         wave_lds_sync();
         cmps += m;
+        if (pre_ok && A.gstride <= PANN_WAVE) {             // one chunk per row: nothing more is inserted before the next vertex
+          pp_h = hash64_2(pre_row) & mask;
+          pp_e = (pre_row != SENTINEL && pre_row != self) ? rs_load(T + pp_h) : 0ull;
+          pp_ok = true;
+        }
         score_and_append(m);
         wave_lds_sync();
       }
