@@ -138,3 +138,38 @@ def test_range_search_large_balls_take_the_worst_case_table_pass(oracle):
     assert oracle.range_search(X, G, s["ids"], r_big, n, queries=Q)["dist_cmps"].max() > 8192
     ix.close()
 
+
+def test_range_search_random_cases(oracle):
+    """seeded sweep: element type, metric, degree (rows longer than one wave), radius from tiny to most of the data set,
+    capacity from 1 up, shared / per-query / padded / repeated starts, external and base-point queries"""
+    rng = np.random.default_rng(99)
+    for it in range(24):
+        dtype = [np.uint8, np.int8, np.float16, np.float32][it % 4]
+        metric = "mips" if dtype == np.int8 and it % 8 == 1 else "l2"
+        d = int(rng.choice([16, 48, 100, 128])); n = int(rng.integers(500, 4000)); R = int(rng.choice([8, 24, 64, 80]))
+        X, Q, G = _setup(oracle, n, d, dtype, metric, R=R)
+        Q = Q[: int(rng.integers(1, 60))]
+        ix = DeviceIndex(X, G, metric=metric)
+        rank = int(rng.choice([1, 5, 30, 200, min(n - 1, 1500)]))
+        gd = oracle.bruteforce_knn(X, Q, rank, metric)[1]
+        r2 = float(np.median(gd[:, -1]))
+        cap = int(rng.choice([1, 7, 64, 700, n]))
+        ns = int(rng.choice([1, 3, 10, 70]))
+        base = it % 3 == 0                                     # base-point queries skip their own vertex
+        nq = len(Q)
+        qid = rng.choice(n, nq, replace=False).astype(np.uint32)
+        if it % 2:
+            starts = rng.integers(0, n, (nq, ns)).astype(np.uint32)          # per query, repeats likely
+            starts[rng.random((nq, ns)) < 0.2] = PAD
+        else:
+            starts = rng.integers(0, n, ns).astype(np.uint32)
+        kw = dict(query_ids=qid) if base else dict(queries=Q)
+        o = oracle.range_search(X, G, starts, r2, cap, metric=metric, **kw)
+        g = ix.range_search(starts, r2, cap, **kw)
+        np.testing.assert_array_equal(o["counts"], g["counts"], err_msg=f"case {it}")
+        np.testing.assert_array_equal(o["truncated"], g["truncated"], err_msg=f"case {it}")
+        np.testing.assert_array_equal(o["ids"], g["ids"], err_msg=f"case {it}")
+        ok = o["truncated"] == 0
+        np.testing.assert_array_equal(o["dist_cmps"][ok], g["dist_cmps"][ok], err_msg=f"case {it}")
+        ix.close()
+
