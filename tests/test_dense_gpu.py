@@ -89,6 +89,22 @@ def test_bruteforce_register_list_kernel_valu_types(oracle, monkeypatch, dtype, 
     ix.close()
 
 
+@pytest.mark.parametrize("dtype,k,nsplit", [(np.float16, 10, 6), (np.float16, 100, 5), (np.uint8, 10, 4), (np.uint8, 100, None)])
+def test_bruteforce_many_workgroups_per_cu(oracle, monkeypatch, dtype, k, nsplit):
+    """4 000 queries x 60 000 points: several hundred workgroups, i.e. several of them resident on every CU at once and every
+    piece of a row racing to publish its bound -- the configuration the small cases above never reach"""
+    if nsplit:
+        monkeypatch.setenv("PANN_GT_NSPLIT", str(nsplit))
+    X = _mk(60000, 64, dtype)
+    Q = _mk(4000, 64, dtype, seed=4321)
+    ix = DeviceIndex(X, max_degree=8)
+    gi, gd = ix.bruteforce_knn(Q, k)
+    oi, od = oracle.bruteforce_knn(X, Q, k)
+    np.testing.assert_array_equal(oi, gi)
+    np.testing.assert_array_equal(od, gd)
+    ix.close()
+
+
 def test_bruteforce_random_shapes(oracle, monkeypatch):
     """seeded sweep over (type, metric, d, k, n, nq, pieces): every shape the ground-truth kernels dispatch on -- register
     lists (k > 16), lane lists (k <= 16), one / two segments, the LDS-list fallback for long rows"""
