@@ -89,7 +89,8 @@ def test_bruteforce_register_list_kernel_valu_types(oracle, monkeypatch, dtype, 
     ix.close()
 
 
-@pytest.mark.parametrize("dtype,k,nsplit", [(np.float16, 10, 6), (np.float16, 100, 5), (np.uint8, 10, 4), (np.uint8, 100, None)])
+@pytest.mark.parametrize("dtype,k,nsplit", [(np.float16, 10, 6), (np.float16, 100, 5), (np.uint8, 10, 4), (np.uint8, 100, None),
+                                             (np.float16, 16, 3), (np.float16, 17, 3), (np.float32, 10, 4), (np.int8, 1, 5)])
 def test_bruteforce_many_workgroups_per_cu(oracle, monkeypatch, dtype, k, nsplit):
     """4 000 queries x 60 000 points: several hundred workgroups, i.e. several of them resident on every CU at once and every
     piece of a row racing to publish its bound -- the configuration the small cases above never reach"""
