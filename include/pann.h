@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define PANN_ABI_VERSION 2
+#define PANN_ABI_VERSION 3
 
 /* status codes */
 #define PANN_OK 0
@@ -145,6 +145,9 @@ int pann_index_set_graph(pann_index* idx, const uint32_t* graph);
  * graph.h:84-99).  Must not overlap a search on the same handle (vamana/index.h:247-270). */
 int pann_index_update_rows(pann_index* idx, const uint32_t* row_ids, const uint32_t* rows,
                            uint64_t m);
+/* Empty graph again (all degrees 0, as Graph(maxDeg, n) gives, graph.h:145-147) without a host slab: one fill on the handle's
+ * stream.  A rebuild of the same points (bench.py's build modes) starts from it. */
+int pann_index_clear_graph(pann_index* idx);
 /* Copy the device graph back to a host n x (max_deg+1) slab. */
 int pann_index_get_graph(pann_index* idx, uint32_t* graph_out);
 
@@ -294,6 +297,12 @@ int pann_range_search(pann_index* idx, const void* queries, const uint32_t* quer
  * DESIGN.md "Build determinism".  times3 (optional): seconds spent in {tree, leaf kNN, MST}. */
 int pann_hcnng_build(pann_index* idx, uint32_t num_clusters, uint32_t cluster_size, uint32_t mst_deg,
                      uint64_t seed, double* times3);
+/* Per-handle tuning knobs; results never depend on them (0 = the library's own choice).  Unknown names: PANN_ERR_BAD_ARG.
+ *   "forest_group": HCNNG -- the independent cluster trees (clusterEdge.h:146-153) are split level by level in groups of this
+ *                   many trees (scratch: trees x n positions; default: as many as 2^31 positions allow)
+ *   "gt_pieces"   : pann_bruteforce_knn -- the base is cut into this many pieces per 64-query tile (default: the count that
+ *                   fills whole rounds of the 256 CUs best) */
+int pann_index_set_option(pann_index* idx, const char* name, int64_t value);
 
 /* Sharded index: d_ids / d_dists hold nlists result lists per query, [nlists][nq][k_in] (global
  * ids; 0xFFFFFFFF = unused slot) -- the output of one all-gather of every shard's top-k; out = per query the k_out smallest

@@ -23,7 +23,7 @@ PANN_U8, PANN_I8, PANN_F32, PANN_F16, PANN_BF16 = 0, 1, 2, 3, 4
 PANN_L2, PANN_MIPS = 0, 1
 PANN_OK = 0
 PANN_ERR_OVERFLOW = 5
-PANN_ABI_VERSION = 2
+PANN_ABI_VERSION = 3
 PANN_STATUS_VISITED_OVERFLOW, PANN_STATUS_DROPPED_OVERFLOW = 1, 2
 
 u32p = C.POINTER(C.c_uint32)
@@ -74,6 +74,8 @@ SIGNATURES = {
     "pann_index_set_graph": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pann_index_update_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "pann_index_get_graph": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pann_index_clear_graph": (C.c_int, [C.c_void_p]),
+    "pann_index_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "pann_batch_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
                                     C.c_uint32, C.POINTER(QueryParams), C.POINTER(SearchOut)]),
     "pann_batch_search_per_query_starts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,

@@ -69,6 +69,7 @@ struct pann_index {
   Workspace ws, ws2, ws3, ws4;   // kernel scratch (search / prune / re-prune / rows of a batch)
   uint32_t vcap = 0;        // visited-list capacity used by the builder (grows on overflow)
   uint32_t dcap = 256;      // dropped-list capacity of the searches (pann_index_reserve_dropped; grows on overflow)
+  uint32_t gt_pieces = 0;   // pann_index_set_option("gt_pieces"): pieces of the base per query tile in pann_bruteforce_knn (0 = auto)
   DevBuf stage[12];      // staging for host-pointer calls
   PinnedBuf pin_in, pin_out;   // packed pinned staging of pann_batch_search
 };
@@ -314,6 +315,24 @@ int pann_index_update_rows(pann_index* idx, const uint32_t* row_ids, const uint3
     if (row_ids[i] >= idx->ix.n) { set_error("ERROR: graph index out of range"); return PANN_ERR_BAD_ARG; }  // graph.h:235-238
   DeviceGuard g(idx->device);
   return upload_graph_rows(idx, rows, m, row_ids);
+}
+
+int pann_index_clear_graph(pann_index* idx) {
+  if (int rc = check_idx(idx, "pann_index_clear_graph")) return rc;
+  DeviceGuard g(idx->device);
+  PANN_HIP(hipMemsetAsync(idx->ix.graph, 0xFF, (size_t)idx->ix.n * idx->ix.gstride * 4, idx->stream));
+  PANN_HIP(hipStreamSynchronize(idx->stream));
+  return PANN_OK;
+}
+
+int pann_index_set_option(pann_index* idx, const char* name, int64_t value) {
+  if (int rc = check_idx(idx, "pann_index_set_option")) return rc;
+  const std::string nm = name ? name : "";
+  if (value < 0 || value > 0x7FFFFFFF) { set_error("pann_index_set_option: value out of range"); return PANN_ERR_BAD_ARG; }
+  if (nm == "forest_group") idx->ix.forest_group = (uint32_t)value;
+  else if (nm == "gt_pieces") idx->gt_pieces = (uint32_t)value;
+  else { set_error("pann_index_set_option: unknown option '" + nm + "'"); return PANN_ERR_BAD_ARG; }
+  return PANN_OK;
 }
 
 int pann_index_get_graph(pann_index* idx, uint32_t* graph_out) {
@@ -784,7 +803,7 @@ int pann_bruteforce_knn(pann_index* idx, const void* queries, uint64_t nq, uint6
       if (fill > best + 1e-9) { best = fill; want = sp; }
     }
   }
-  const uint32_t env_split = getenv("PANN_GT_NSPLIT") ? (uint32_t)atoi(getenv("PANN_GT_NSPLIT")) : 0u;      // diagnostic A/B switch
+  const uint32_t env_split = idx->gt_pieces;      // pann_index_set_option("gt_pieces")
   uint32_t nsplit = std::max<uint32_t>(1, std::min<uint32_t>(env_split ? env_split : want, (uint32_t)((idx->ix.n + 4095) / 4096)));
   nsplit = std::min<uint32_t>(nsplit, 64);
   if (int rc = dense_topk_dev(idx->ix, idx->ws2, st, idx->stage[2].as<uint8_t>(), q_stride_bytes, nullptr, nullptr, nullptr,

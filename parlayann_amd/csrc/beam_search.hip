@@ -1102,7 +1102,7 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
 // the reference's own row alignment, point_range.h:94) or LPC=16 for long rows.
 void choose_point_layout(uint32_t dbytes, uint32_t* lpc, uint32_t* nch) {
   const uint32_t r64 = (dbytes + 63) / 64 * 64;
-  if (const char* f = getenv("PANN_FORCE_LPC")) {          // diagnostic A/B switch: lanes per candidate 4 / 8 / 16
+  if (const char* f = ab_env("PANN_FORCE_LPC")) {          // diagnostic A/B switch: lanes per candidate 4 / 8 / 16
     const uint32_t l = (uint32_t)atoi(f);
     if ((l == 4 || l == 8 || l == 16) && r64 % (l * 16) == 0 && r64 / (l * 16) > 1) { *lpc = l; *nch = r64 / (l * 16); return; }
   }
@@ -1157,14 +1157,14 @@ static Plan make_plan(const DeviceIndex& ix, const SearchArgs& a) {
     // (Infinity-Cache resident): one dependent load per adjacency row, 3x the queries per CU; measured +17 % on the
     // C3 build's search phase and +10 % on beam-128 queries -- the 64 single-word table requests per row make the
     // L2 request rate the new limit (in-kernel stamps: every phase 2-3x longer at 3x the occupancy).
-    static const bool force_lds = getenv("PANN_B128_LDS") != nullptr;       // diagnostic A/B switch
+    static const bool force_lds = ab_env("PANN_B128_LDS") != nullptr;       // diagnostic A/B switch
     p.b128_hbm = (hbytes > 8192) && a.nq > 2048 && !force_lds;
     p.hsplit = 0;
     if (p.b128_hbm) {   // one table per block, >= the resident waves
-      static const char* sp = getenv("PANN_B128_SPLIT");
+      static const char* sp = ab_env("PANN_B128_SPLIT");
       p.hsplit = sp ? (uint32_t)atoi(sp) : 1u;     // measured: half in LDS 2.99 M q/s, none 2.46, three quarters 2.67, whole table in LDS 2.28
       if (p.hsplit > 3) p.hsplit = 0;
-      static const bool no24 = getenv("PANN_B128_NO24") != nullptr;              // diagnostic A/B switch
+      static const bool no24 = ab_env("PANN_B128_NO24") != nullptr;              // diagnostic A/B switch
       if (p.hsplit == 3 && (no24 || !(ix.n < 0xFFFFFFull))) p.hsplit = 1;     // the all-LDS mode exists for 24-bit planes only
       p.hash_lds = false; p.slots = 256 * 32;
       p.p24 = (p.hsplit && ix.n < 0xFFFFFFull && !no24) ? 1u : 0u;
@@ -1261,7 +1261,7 @@ int launch_beam_search(const DeviceIndex& ix, const SearchArgs& a, void* ws, siz
   P.work_counter = (uint32_t*)w; P.status = (uint32_t*)(w + 64);
   P.dropped = (uint64_t*)(w + 256); P.dcap = p.dcap;
   {
-    static const char* pf = getenv("PANN_PRIO_FROM");              // A/B switch: tenths of the grid without priority (default 8; 10 = off)
+    static const char* pf = ab_env("PANN_PRIO_FROM");              // A/B switch: tenths of the grid without priority (default 8; 10 = off)
     const uint32_t tenths = pf ? (uint32_t)atoi(pf) : 8u;
     P.prio_start = tenths >= 10 ? 0xFFFFFFFFu : (uint32_t)((uint64_t)a.nq * tenths / 10);
   }
@@ -1289,7 +1289,7 @@ int launch_beam_search(const DeviceIndex& ix, const SearchArgs& a, void* ws, siz
   // the status word follows the results on the launch stream (pann_search_out::status, device pointer here)
   if (a.out.status) PANN_HIP(hipMemcpyAsync(a.out.status, P.status, 4, hipMemcpyDeviceToDevice, stream));
 #ifdef PANN_STAMPS
-  if (getenv("PANN_STAMPS_PRINT") && a.nq >= 1000) {
+  if (ab_env("PANN_STAMPS_PRINT") && a.nq >= 1000) {
     (void)hipStreamSynchronize(stream);
     std::vector<unsigned long long> h(a.nq * 8);
     (void)hipMemcpy(h.data(), P.stamps, a.nq * 64, hipMemcpyDeviceToHost);

@@ -1188,7 +1188,7 @@ constexpr size_t GT_LDS_BYTES = 2 * (size_t)GT_BT_BYTES + 2 * DT_B * sizeof(floa
 // lane-list kernels above, 0.167 s vs 0.121 s for 30 trees over 1M x 128 fp16: a row sees so few columns that 5.6 % of them
 // enter its list, and 64 lane-owned lists take that in parallel where the quarter lists take four at a time.)
 bool dense_gt_eligible(const DeviceIndex& ix, uint32_t m, bool b_ids, bool segmented, int exclude_same) {
-  static const bool off = getenv("PANN_GT_OLD") != nullptr;      // diagnostic A/B switch
+  static const bool off = ab_env("PANN_GT_OLD") != nullptr;      // diagnostic A/B switch
   if (off || m == 0 || m > 128 || ix.exact || b_ids || segmented || exclude_same) return false;
   const bool twobyte = ix.dtype == PANN_F16 || ix.dtype == PANN_BF16;
   return twobyte ? ix.pstride <= 256 : ix.pstride <= 512;        // matrix cores: one 256-byte segment; VALU register tile: two

@@ -383,7 +383,7 @@ int hcnng_build_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, uint32
   // TOGETHER -- one ids array of group*n positions, clusters of every tree in one launch -- so a level costs one
   // host round trip for the whole forest instead of one per tree.  Positions are 32-bit: group*n < 2^31.
   uint32_t group = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(num_clusters, (1ull << 31) / std::max<uint64_t>(n, 1)));
-  if (const char* g = getenv("PANN_HCNNG_GROUP")) group = std::max<uint32_t>(1, std::min<uint32_t>(group, (uint32_t)atoi(g)));   // test hook: smaller forests
+  if (ix.forest_group) group = std::min<uint32_t>(group, ix.forest_group);   // pann_index_set_forest_group: bounds the forest's scratch
   const uint64_t gn = (uint64_t)group * n;
   ABuf b_ids, b_new, b_first, b_scan, b_pos, b_deg, b_leaflo, b_nnids, b_nnd, b_ka, b_kb, b_par, b_rnk, b_dgr, b_tmp;
   ABuf d_sc, d_tbase, d_same, d_scat, d_n0, d_loff, d_seg_b, d_seg_e;

@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(128) leaf_knn_kernel(LeafArgs A) {
 }
 
 bool leaf_knn_rows_eligible(const DeviceIndex& ix, uint32_t m) {
-  static const bool off = getenv("PANN_LEAF_OLD") != nullptr;                 // diagnostic A/B switch: the round-1 kernel
+  static const bool off = ab_env("PANN_LEAF_OLD") != nullptr;                 // diagnostic A/B switch: the round-1 kernel
   return !off && (ix.dtype == PANN_U8 || ix.dtype == PANN_I8) && ix.pstride <= 256 && m >= 1 && m <= 16;
 }
 
@@ -220,11 +220,15 @@ int leaf_knn_rows_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, cons
   A.points = ix.points; A.pstride = ix.pstride; A.ids = d_ids; A.off = d_off; A.tile_seg = d_tseg; A.tile_a0 = d_ta0;
   A.m = m; A.exclude_same_id = exclude_same; A.out_ids = d_out_ids; A.out_dists = d_out_dists;
   const uint32_t nch = (ix.dbytes + 15) / 16;                                  // chunks that hold data (the rest is zero padding)
+  // every instantiation reads NCH * 16 bytes of a row: the NCH chosen below must not exceed the row stride (64-byte granules:
+  // 4 -> 64, 8 -> 128, 12 -> 192, 13 and 16 -> 256), or the sums would take in the head of the next row
+  if (ix.pstride % 64 != 0 || nch * 16 > ix.pstride) return PANN_ERR_BAD_ARG;
 #define LK_LAUNCH(DT, MT, NCH, MC) hipLaunchKernelGGL((leaf_knn_kernel<DT, MT, NCH, MC>), dim3((uint32_t)nt), dim3(128), 0, st, A)
 #define LK_NCH(DT, MT, MC)                                  \
   do {                                                      \
     if (nch <= 4) LK_LAUNCH(DT, MT, 4, MC);                 \
     else if (nch <= 8) LK_LAUNCH(DT, MT, 8, MC);            \
+    else if (nch <= 12) LK_LAUNCH(DT, MT, 12, MC);          \
     else if (nch <= 13) LK_LAUNCH(DT, MT, 13, MC);          \
     else LK_LAUNCH(DT, MT, 16, MC);                         \
   } while (0)

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string>
 
 #include "../../include/pann.h"
@@ -10,6 +11,14 @@
 namespace pann {
 
 constexpr uint32_t SENTINEL = 0xFFFFFFFFu;  // empty adjacency slot on the device / empty filter slot
+
+// Diagnostic A/B switches (environment variables that select kernel variants for same-box comparisons, tools/ab_*.sh) exist
+// only in `make alt` builds (-DPANN_AB, lib/libpann_alt.so); the shipped libpann.so reads no environment variable.
+#ifdef PANN_AB
+inline const char* ab_env(const char* name) { return getenv(name); }
+#else
+inline const char* ab_env(const char*) { return nullptr; }
+#endif
 
 // ---- device-side layout of one index (DESIGN.md "Data layout in HBM") ----
 //  points: n rows, row stride pstride = nch * lpc * 16 bytes (>= d*esize), zero padded
@@ -30,6 +39,7 @@ struct DeviceIndex {
   uint32_t exact = 0;    // exact float order (validation mode): lane-per-candidate sequential sums; forces lpc=4
   uint32_t max_deg = 0;
   uint32_t gstride = 0;  // uint32 per graph row on the device
+  uint32_t forest_group = 0;  // HCNNG: trees split level by level together (0 = as many as 2^31 positions allow)
 };
 
 // The kernels come in two families (PANN_LAYOUT_SWITCH): rows that are ONE 16-byte chunk per lane with 8 / 16 / 32

@@ -529,7 +529,7 @@ static int run_prune(const DeviceIndex& ix, PruneArgs pa, GreedyArgs ga, uint64_
   PANN_HIP(rocprim::segmented_radix_sort_keys(sort_tmp, sort_tmp_bytes, keys_a, keys_b, total_keys, m,
                                               (const uint32_t*)pa.seg_begin, (const uint32_t*)pa.seg_end, 0, 64, st));
   ga.keys = keys_b; ga.seg_begin = pa.seg_begin; ga.seg_end = pa.seg_end;
-  { static const char* sp = getenv("PANN_PRUNE_SINGLE"); ga.single_pick = sp ? (uint32_t)atoi(sp) : 0u; }   // A/B switch: 1 one pick per pass, 2 lists in HBM
+  { static const char* sp = ab_env("PANN_PRUNE_SINGLE"); ga.single_pick = sp ? (uint32_t)atoi(sp) : 0u; }   // A/B switch: 1 one pick per pass, 2 lists in HBM
   ga.kcap = std::min<uint32_t>((max_seg_len + 63) / 64 * 64, 3072);                       // <= 24 KB of keys per wave
   const size_t gb_lds = qb * PANN_PRUNE_PB + (size_t)((ga.R + 3) & ~3u) * 4 + (size_t)ga.kcap * 8;      // PB query slots
 #define CALL_GREEDY(DT, MT, L, N1) hipLaunchKernelGGL((prune_greedy_kernel<DT, MT, L, N1>), dim3(m), dim3(PANN_WAVE), gb_lds, st, ga)

@@ -172,6 +172,14 @@ class DeviceIndex:
         assert rows.shape == (len(row_ids), self.max_degree + 1)
         check(self._lib.pann_index_update_rows(self._h, _ptr(row_ids), _ptr(rows), len(row_ids)))
 
+    def clear_graph(self):
+        """empty graph again (Graph(maxDeg, n), graph.h:145-147), on the device"""
+        check(self._lib.pann_index_clear_graph(self._h))
+
+    def set_option(self, name, value):
+        """pann_index_set_option: per-handle tuning knobs ("forest_group", "gt_pieces"); results never depend on them"""
+        check(self._lib.pann_index_set_option(self._h, name.encode(), int(value)))
+
     def get_graph(self):
         g = np.empty((self.n, self.max_degree + 1), dtype=np.uint32)
         check(self._lib.pann_index_get_graph(self._h, _ptr(g)))

@@ -25,7 +25,7 @@ def test_header_symbols_are_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/pann.h but not exported by libpann.so"
     assert sorted(_capi.SIGNATURES) == names
-    assert _capi.load().pann_abi_version() == 2
+    assert _capi.load().pann_abi_version() == 3
 
 
 def test_struct_layouts_match_header():

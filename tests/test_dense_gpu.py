@@ -31,6 +31,29 @@ def test_leaf_knn(oracle, dtype, metric, d):
     ix.close()
 
 
+@pytest.mark.parametrize("dtype", [np.uint8, np.int8])
+@pytest.mark.parametrize("metric", ["l2", "mips"])
+@pytest.mark.parametrize("d", [33, 64, 65, 129, 144, 160, 192, 193, 208, 209, 256])
+def test_leaf_knn_one_byte_every_row_stride(oracle, dtype, metric, d):
+    """one-byte rows of 129..192 bytes have a 192-byte stride; the lane-owns-row kernel must not read a
+    13th chunk there (it belongs to the next row; for the last row it lies past the slab).  n is a multiple of 64 and the
+    leaves hold the table's last rows."""
+    n = 2048
+    X = _mk(n, d, dtype, seed=77 + d)
+    ix = DeviceIndex(X, max_degree=8, metric=metric)
+    rng = np.random.default_rng(d)
+    leaves = [np.arange(n - 300, n, dtype=np.uint32), rng.choice(n, 257, replace=False).astype(np.uint32),
+              np.array([n - 1, 0, n - 2], dtype=np.uint32)]
+    sizes = [len(l) for l in leaves]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    gi, gd = ix.leaf_knn_batch(np.concatenate(leaves), off, 10)
+    for li, ids in enumerate(leaves):
+        oi, od = oracle.leaf_knn(X, ids, 10, metric=metric)
+        np.testing.assert_array_equal(oi, gi[off[li]:off[li + 1]], err_msg=f"leaf {li} size {len(ids)}")
+        np.testing.assert_array_equal(od.view(np.uint32), gd[off[li]:off[li + 1]].view(np.uint32))
+    ix.close()
+
+
 @pytest.mark.parametrize("dtype,metric,d,k", [(np.uint8, "l2", 128, 100), (np.float16, "l2", 128, 10),
                                               (np.int8, "mips", 200, 100), (np.float32, "l2", 96, 37),
                                               (np.float16, "mips", 128, 100), (np.float16, "l2", 200, 64)])
@@ -38,6 +61,7 @@ def test_bruteforce_knn(oracle, dtype, metric, d, k):
     X = _mk(20000, d, dtype)
     Q = _mk(130, d, dtype, seed=4321)
     ix = DeviceIndex(X, max_degree=8, metric=metric)
+    ix.set_option("gt_pieces", nsplit or 0)
     gi, gd = ix.bruteforce_knn(Q, k)
     oi, od = oracle.bruteforce_knn(X, Q, k, metric=metric)
     np.testing.assert_array_equal(oi, gi)
@@ -51,15 +75,14 @@ def test_bruteforce_knn(oracle, dtype, metric, d, k):
     ("l2", 64, 100, 6000, 70, None), ("l2", 100, 50, 6000, 70, None), ("l2", 32, 100, 700, 20, 5),
     ("l2", 128, 100, 50, 10, None), ("l2", 128, 100, 64, 64, 1), ("mips", 96, 30, 129, 3, 2),
 ])
-def test_bruteforce_register_list_kernel(oracle, monkeypatch, metric, d, k, n, nq, nsplit):
+def test_bruteforce_register_list_kernel(oracle, metric, d, k, n, nq, nsplit):
     """two-byte floats, rows <= 256 bytes, k in 17..128: dense_gt_mfma_kernel (lists in registers, B double-buffered);
     partial tiles, fewer points than k, one query, every piece count"""
-    if nsplit:
-        monkeypatch.setenv("PANN_GT_NSPLIT", str(nsplit))
     X = _mk(n, d, np.float16)
     Q = _mk(nq, d, np.float16, seed=4321)
     X[n // 2] = X[n // 3]                      # equal distances: the id decides (check_nn_recall-style ties)
     ix = DeviceIndex(X, max_degree=8, metric=metric)
+    ix.set_option("gt_pieces", nsplit or 0)
     gi, gd = ix.bruteforce_knn(Q, k)
     oi, od = oracle.bruteforce_knn(X, Q, k, metric=metric)
     np.testing.assert_array_equal(oi, gi)
@@ -73,15 +96,14 @@ def test_bruteforce_register_list_kernel(oracle, monkeypatch, metric, d, k, n, n
     (np.float32, "l2", 96, 100, 9000, 70, None), (np.float32, "mips", 128, 37, 6000, 129, 2), (np.float32, "l2", 20, 100, 3000, 5, None),
     (np.uint8, "l2", 128, 100, 50, 3, None), (np.float32, "l2", 65, 30, 200, 64, 1),
 ])
-def test_bruteforce_register_list_kernel_valu_types(oracle, monkeypatch, dtype, metric, d, k, n, nq, nsplit):
+def test_bruteforce_register_list_kernel_valu_types(oracle, dtype, metric, d, k, n, nq, nsplit):
     """one-byte types and f32, rows <= 512 bytes, k in 17..128: dense_gt_valu_kernel (v_dot4 / fma register tile in the MFMA's
     output layout, the same register lists); one and two 256-byte segments, rows that end inside a 16-byte chunk"""
-    if nsplit:
-        monkeypatch.setenv("PANN_GT_NSPLIT", str(nsplit))
     X = _mk(n, d, dtype)
     Q = _mk(nq, d, dtype, seed=4321)
     X[n // 2] = X[n // 3]
     ix = DeviceIndex(X, max_degree=8, metric=metric)
+    ix.set_option("gt_pieces", nsplit or 0)
     gi, gd = ix.bruteforce_knn(Q, k)
     oi, od = oracle.bruteforce_knn(X, Q, k, metric=metric)
     np.testing.assert_array_equal(oi, gi)
@@ -91,14 +113,13 @@ def test_bruteforce_register_list_kernel_valu_types(oracle, monkeypatch, dtype, 
 
 @pytest.mark.parametrize("dtype,k,nsplit", [(np.float16, 10, 6), (np.float16, 100, 5), (np.uint8, 10, 4), (np.uint8, 100, None),
                                              (np.float16, 16, 3), (np.float16, 17, 3), (np.float32, 10, 4), (np.int8, 1, 5)])
-def test_bruteforce_many_workgroups_per_cu(oracle, monkeypatch, dtype, k, nsplit):
+def test_bruteforce_many_workgroups_per_cu(oracle, dtype, k, nsplit):
     """4 000 queries x 60 000 points: several hundred workgroups, i.e. several of them resident on every CU at once and every
     piece of a row racing to publish its bound -- the configuration the small cases above never reach"""
-    if nsplit:
-        monkeypatch.setenv("PANN_GT_NSPLIT", str(nsplit))
     X = _mk(60000, 64, dtype)
     Q = _mk(4000, 64, dtype, seed=4321)
     ix = DeviceIndex(X, max_degree=8)
+    ix.set_option("gt_pieces", nsplit or 0)
     gi, gd = ix.bruteforce_knn(Q, k)
     oi, od = oracle.bruteforce_knn(X, Q, k)
     np.testing.assert_array_equal(oi, gi)
@@ -106,7 +127,7 @@ def test_bruteforce_many_workgroups_per_cu(oracle, monkeypatch, dtype, k, nsplit
     ix.close()
 
 
-def test_bruteforce_random_shapes(oracle, monkeypatch):
+def test_bruteforce_random_shapes(oracle):
     """seeded sweep over (type, metric, d, k, n, nq, pieces): every shape the ground-truth kernels dispatch on -- register
     lists (k > 16), lane lists (k <= 16), one / two segments, the LDS-list fallback for long rows"""
     rng = np.random.default_rng(20260)
@@ -117,10 +138,11 @@ def test_bruteforce_random_shapes(oracle, monkeypatch):
         d = int(rng.choice([8, 20, 64, 96, 100, 128, 200, 256]))
         k = int(rng.choice([1, 10, 16, 17, 33, 64, 100, 128]))
         n = int(rng.integers(1, 3000)); nq = int(rng.integers(1, 150))
-        monkeypatch.setenv("PANN_GT_NSPLIT", str(int(rng.integers(1, 6))))
+        pieces = int(rng.integers(1, 6))
         X = _mk(n, d, dtype, seed=int(rng.integers(1 << 30)))
         Q = _mk(nq, d, dtype, seed=int(rng.integers(1 << 30)))
         ix = DeviceIndex(X, max_degree=8, metric=metric)
+        ix.set_option("gt_pieces", pieces)
         gi, gd = ix.bruteforce_knn(Q, k)
         oi, od = oracle.bruteforce_knn(X, Q, k, metric=metric)
         tag = f"case {it}: {np.dtype(dtype).name} {metric} d={d} k={k} n={n} nq={nq}"

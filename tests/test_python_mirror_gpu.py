@@ -3,7 +3,7 @@ quantised search + rerank) over the C-ABI, checked against compositions of oracl
 import numpy as np
 import pytest
 
-from parlayann_amd import datasets, io, quantize, wrapper
+from parlayann_amd import DeviceIndex, datasets, io, quantize, wrapper
 
 pytestmark = pytest.mark.gpu
 
@@ -172,7 +172,8 @@ def test_search_and_parse_sweep(oracle):
     ix.close()
 
 
-@pytest.mark.parametrize("dtype,metric,d", [(np.uint8, "Euclidian", 128), (np.int8, "mips", 200), (np.float16, "Euclidian", 96)])
+@pytest.mark.parametrize("dtype,metric,d", [(np.uint8, "Euclidian", 128), (np.int8, "mips", 200), (np.float16, "Euclidian", 96),
+                                            (np.uint8, "Euclidian", 160), (np.int8, "mips", 192)])   # 192-byte row stride
 def test_hcnng_build_identical_to_oracle(oracle, dtype, metric, d):
     """host tree + Kruskal around the device calls (pivot split, leaf kNN) vs. the all-CPU oracle:
     same seeding rules, integer-valued data -> the graphs must be identical, slot for slot."""
@@ -195,13 +196,21 @@ def test_hcnng_build_leaf_size_extremes(oracle, n, clusters, leaf, mst_deg):
     np.testing.assert_array_equal(G, Go)
 
 
-def test_hcnng_forest_groups_give_the_same_graph(oracle, monkeypatch):
-    """trees are split level by level in groups (all of them when group * n < 2^31); the grouping must not matter"""
+def test_hcnng_forest_groups_give_the_same_graph(oracle):
+    """trees are split level by level in groups (all of them when group * n < 2^31; pann_index_set_forest_group bounds the
+    scratch); the grouping must not matter"""
     X = datasets.sift_like(4000, 64, seed=3, dtype=np.uint8)
     Go = oracle.hcnng_build(X, 5, 150, 3, seed=4)
-    for g in ("1", "2", "5"):
-        monkeypatch.setenv("PANN_HCNNG_GROUP", g)
-        np.testing.assert_array_equal(wrapper.hcnng_build(X, "Euclidian", 5, 150, 3, seed=4), Go)
+    for g in (1, 2, 5, 0):
+        ix = DeviceIndex(X, max_degree=15)
+        ix.set_option("forest_group", g)
+        ix.hcnng_build(5, 150, 3, seed=4)
+        np.testing.assert_array_equal(ix.get_graph(), Go)
+        ix.clear_graph()                                              # pann_index_clear_graph: the rebuild starts from Graph(maxDeg, n)
+        assert not ix.get_graph().any()
+        ix.hcnng_build(5, 150, 3, seed=4)
+        np.testing.assert_array_equal(ix.get_graph(), Go)
+        ix.close()
 
 
 def test_parlayannpy_dropin_names():
