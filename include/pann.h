@@ -304,11 +304,16 @@ int pann_hcnng_build(pann_index* idx, uint32_t num_clusters, uint32_t cluster_si
  *                   fills whole rounds of the 256 CUs best) */
 int pann_index_set_option(pann_index* idx, const char* name, int64_t value);
 
-/* Sharded index: d_ids / d_dists hold nlists result lists per query, [nlists][nq][k_in] (global
- * ids; 0xFFFFFFFF = unused slot) -- the output of one all-gather of every shard's top-k; out = per query the k_out smallest
- * under (dist, id) (beamSearch.h:46-48).  Device pointers, launched on `stream` of the current device, no synchronisation. */
-int pann_merge_topk_dev(const uint32_t* d_ids, const float* d_dists, uint32_t nlists, uint64_t nq, uint32_t k_in, uint32_t k_out,
-                        uint32_t* d_out_ids, float* d_out_dists, void* stream);
+/* Sharded index: nlists result lists per query -- the output of ONE all-gather of every shard's
+ * top-k -- laid out [nlists][nq][row_stride]: row (w, q) holds k_in ids at d_ids and k_in distances at d_dists (0xFFFFFFFF =
+ * unused slot).  Two separate arrays: row_stride = k_in.  One packed array of [ids | distance bits] rows (what
+ * parlayann_amd.distributed gathers): row_stride = 2 * k_in, d_dists = (float*)(d_ids + k_in).  d_list_base (optional, nlists
+ * words): list w holds ids LOCAL to shard w and gets d_list_base[w] added; NULL: the ids are global.  out = per query the k_out
+ * smallest under (dist, id) (beamSearch.h:46-48).  Device pointers, launched on `stream` of the current device, no
+ * synchronisation. */
+int pann_merge_topk_dev(const uint32_t* d_ids, const float* d_dists, uint32_t nlists, uint64_t nq, uint32_t k_in,
+                        uint32_t row_stride, const uint32_t* d_list_base, uint32_t k_out, uint32_t* d_out_ids, float* d_out_dists,
+                        void* stream);
 
 /* HCNNG with the TREES split over GPUs (the cluster trees are independent,
  * clusterEdge.h:146-153): every rank holds all points; rank r builds trees r, r + W, r + 2W, ... of the forest that

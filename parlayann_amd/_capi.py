@@ -107,8 +107,8 @@ SIGNATURES = {
                               C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
     "pann_pivot_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pann_hcnng_build": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p]),
-    "pann_merge_topk_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
-                                      C.c_void_p]),
+    "pann_merge_topk_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "pann_hcnng_build_trees_dev": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                              C.c_void_p, C.c_uint32, C.c_void_p]),
     "pann_hcnng_assemble_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),

@@ -4,8 +4,8 @@ translates reference code.
 
   * replicated index, sharded queries  : no collective on the data path (bench.py); only a barrier
     and a max-reduce of the elapsed time (`timed_steps`).
-  * sharded index (C4)                 : every rank searches ALL queries on its own id range; one
-    all-gather of the per-rank top-k (k*8 B per query per rank) and a merge by (dist,id).
+  * sharded index (C4)                 : every rank searches ALL queries on its own id range; ONE
+    all-gather of the per-rank packed top-k rows (k*8 B per query per rank) and a merge by (dist,id).
   * sharded Vamana build               : points and graph replicated, every BATCH of batch_insert split over the ranks;
     ONE all-gather of the batch's new adjacency rows (m x R x 4 B) per batch stitches the replicas back together
     (`vamana_build_sharded`).  The graph is bit-identical to the single-GPU build.
@@ -119,9 +119,9 @@ class ShardedIndex:
 class DeviceShardedIndex:
     """The sharded index on the product path, nothing on the host between the kernels: rank r holds base points
     [lo, hi) as a DeviceIndex with its own sub-graph (local ids); a query batch (a device tensor, the same on every rank)
-    is searched on every shard (pann_batch_search_dev), the local ids get the shard base added, ONE all-gather moves
-    every rank's [nq, k] ids and distances (k * 8 bytes per query per rank) and pann_merge_topk_dev keeps the k smallest
-    by (dist, id).  Results stay in HBM (torch tensors)."""
+    is searched on every shard (pann_batch_search_dev); ONE all-gather moves every rank's packed [nq, 2k] rows (k local ids |
+    k distance bits: k * 8 bytes per query per rank) and pann_merge_topk_dev adds each shard's base to its ids and keeps the
+    k smallest by (dist, id).  Results stay in HBM (torch tensors)."""
 
     def __init__(self, points, max_degree, build, device_ordinal=0, metric="Euclidian", n_total=None):
         """points: the whole base (every rank slices its own range out of it), or -- with n_total given -- only this rank's
@@ -136,42 +136,66 @@ class DeviceShardedIndex:
         build(self.ix)
         self.dev = torch.device("cuda", device_ordinal)
         self._starts = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self._status = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        bases = [shard_range(self.n, r, self.world)[0] for r in range(self.world)]
+        self._bases = torch.from_numpy(np.array(bases, dtype=np.uint32).view(np.int32)).to(self.dev)     # uint32 bit patterns
+        self.collectives = 0            # all-gathers issued so far (tests assert ONE per search)
+        self.last_counters = None       # (visited_count, dist_cmps, degree_sum) device tensors of the last local search
 
-    def _merge(self, ids, dists, k):
-        """local [nq, kk] (local ids, int32 view of uint32) -> global top-k over all ranks, on the device"""
+    def _merge(self, packed, k):
+        """packed: local [nq, 2*kk] int32 rows (kk local ids | kk distance bits) -> global top-k over all ranks, on the device;
+        ONE all-gather"""
         import ctypes as C
         from ._capi import check
-        nq = ids.shape[0]
-        gids = torch.where(ids == -1, ids, ids + self.lo)                   # -1 == 0xFFFFFFFF: unused slot of a short list
-        all_i = all_gather_tensor(gids)                                     # [W, nq, kk]
-        all_d = all_gather_tensor(dists)
+        nq, kk = packed.shape[0], packed.shape[1] // 2
+        allp = all_gather_tensor(packed)                                    # [W, nq, 2*kk]
+        self.collectives += 1
         oi = torch.empty((nq, k), dtype=torch.int32, device=self.dev)
         od = torch.empty((nq, k), dtype=torch.float32, device=self.dev)
         st = torch.cuda.current_stream(self.dev)
-        check(self.ix._lib.pann_merge_topk_dev(all_i.data_ptr(), all_d.data_ptr(), all_i.shape[0], nq, ids.shape[1], k, oi.data_ptr(),
-                                               od.data_ptr(), C.c_void_p(st.cuda_stream)))
+        check(self.ix._lib.pann_merge_topk_dev(allp.data_ptr(), allp.data_ptr() + 4 * kk, allp.shape[0], nq, kk, 2 * kk,
+                                               self._bases.data_ptr(), k, oi.data_ptr(), od.data_ptr(), C.c_void_p(st.cuda_stream)))
         return oi, od
 
     def bruteforce(self, queries, k):
         """exact ground truth over all shards (not a timed path: the per-shard brute force takes host arrays)"""
         li, ld = self.ix.bruteforce_knn(queries, k)
-        return self._merge(torch.from_numpy(li.view(np.int32)).to(self.dev), torch.from_numpy(ld).to(self.dev), k)
+        packed = torch.from_numpy(np.concatenate([li.view(np.int32), ld.view(np.int32)], axis=1)).to(self.dev)
+        return self._merge(packed, k)
 
-    def search(self, d_queries, k, beam, cut=1.35):
+    def search(self, d_queries, k, beam, cut=1.35, limit=None, counters=False):
         """d_queries: [nq, row bytes] uint8 device tensor (raw rows of the index dtype).  Returns (ids, dists) device tensors
-        [nq, k] (int32 holding uint32 ids, float32)."""
+        [nq, k] (int32 holding uint32 ids, float32).  The launch's status word (include/pann.h PANN_STATUS_*) is read before the
+        exchange: a dropped-list overflow grows the scratch and runs the local search again (as pann_batch_search does on the
+        host path) -- a rank never gathers lists the kernel has declared invalid."""
         import ctypes as C
-        from ._capi import QueryParams, SearchOut, check
+        from ._capi import PANN_STATUS_DROPPED_OVERFLOW, QueryParams, SearchOut, check
         lib = self.ix._lib
         nq = d_queries.shape[0]
+        packed = torch.empty((nq, 2 * k), dtype=torch.int32, device=self.dev)
         ids = torch.empty((nq, k), dtype=torch.int32, device=self.dev)
         dists = torch.empty((nq, k), dtype=torch.float32, device=self.dev)
-        qp = QueryParams(k=k, beam=beam, cut=cut, limit=self.ix.n, degree_limit=self.ix.max_degree, rerank_factor=100, pad=1.0)
-        out = SearchOut(ids=ids.data_ptr(), dists=dists.data_ptr(), out_k=k)
+        lim = self.ix.n if limit is None else int(limit)
+        qp = QueryParams(k=k, beam=beam, cut=cut, limit=lim, degree_limit=self.ix.max_degree, rerank_factor=100, pad=1.0)
+        out = SearchOut(ids=ids.data_ptr(), dists=dists.data_ptr(), out_k=k, status=self._status.data_ptr())
+        if counters:
+            self.last_counters = tuple(torch.empty(nq, dtype=torch.int32, device=self.dev) for _ in range(3))
+            out.visited_count, out.dist_cmps, out.degree_sum = (t.data_ptr() for t in self.last_counters)
         st = torch.cuda.current_stream(self.dev)
-        check(lib.pann_batch_search_dev(self.ix.handle, d_queries.data_ptr(), None, nq, d_queries.shape[1], self._starts.data_ptr(), 1,
-                                        C.byref(qp), C.byref(out), C.c_void_p(st.cuda_stream)))
-        return self._merge(ids, dists, k)
+        for attempt in range(2):
+            check(lib.pann_batch_search_dev(self.ix.handle, d_queries.data_ptr(), None, nq, d_queries.shape[1], self._starts.data_ptr(),
+                                            1, C.byref(qp), C.byref(out), C.c_void_p(st.cuda_stream)))
+            status = int(self._status.item())                                 # one host read per search; the exchange follows anyway
+            if not (status & PANN_STATUS_DROPPED_OVERFLOW):
+                break
+            if attempt == 1:
+                raise RuntimeError("DeviceShardedIndex.search: dropped-list overflow persists after reserving min(limit, n) entries")
+            self.ix.reserve_dropped(max(1, min(lim, self.ix.n)))              # a query drops at most one entry per visit
+        if status:
+            raise RuntimeError(f"DeviceShardedIndex.search: launch status {status} (include/pann.h PANN_STATUS_*)")
+        packed[:, :k] = ids
+        packed[:, k:] = dists.view(torch.int32)
+        return self._merge(packed, k)
 
     def close(self):
         self.ix.close()

@@ -61,7 +61,6 @@ def test_bruteforce_knn(oracle, dtype, metric, d, k):
     X = _mk(20000, d, dtype)
     Q = _mk(130, d, dtype, seed=4321)
     ix = DeviceIndex(X, max_degree=8, metric=metric)
-    ix.set_option("gt_pieces", nsplit or 0)
     gi, gd = ix.bruteforce_knn(Q, k)
     oi, od = oracle.bruteforce_knn(X, Q, k, metric=metric)
     np.testing.assert_array_equal(oi, gi)

@@ -33,6 +33,7 @@ def _worker(rank, world, port, q):
     oi, od = sh.search(d_q, 10, 64)
     torch.cuda.synchronize()
     ids, dists = oi.cpu().numpy().view(np.uint32), od.cpu().numpy()
+    sh_collectives = sh.collectives
     sh.close()
     # ---- sharded Vamana build: points + graph replicated, every batch split over the ranks ----
     Xb = X[:8000]
@@ -46,7 +47,7 @@ def _worker(rank, world, port, q):
     D.device_hcnng_build_tree_parallel(ih, 5, 300, 3, seed=11)
     Gh = ih.get_graph()
     ih.close()
-    q.put((rank, ids, dists, Gv, info["collectives"], info["bytes_gathered"], Gh))
+    q.put((rank, ids, dists, Gv, info["collectives"], info["bytes_gathered"], Gh, sh_collectives))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -90,6 +91,7 @@ def test_sharded_index_equals_per_shard_oracle_merged(two_ranks, oracle):
     for r in range(2):
         np.testing.assert_array_equal(two_ranks[r][1], exp_i)
         np.testing.assert_array_equal(two_ranks[r][2], exp_d)
+        assert two_ranks[r][7] == 1                    # ONE all-gather per search: packed [nq, 2k] rows (ids | distance bits)
     # Recall bar.  Round 1 asserted 0.97, measured 0.968 (200 queries) and lowered the bar to 0.94; the bar is back at 0.97
     # (400 queries: 0.9705, deterministic -- the results above are bit-exact) and the sharded answer is also held against
     # ONE graph over all points searched with the same beam (0.978: two 10K-point graphs are each a little worse than one
@@ -139,9 +141,48 @@ def test_merge_topk_kernel_against_numpy(oracle):
         dev = torch.device("cuda", 0)
         ti = torch.from_numpy(ids.view(np.int32)).to(dev); td = torch.from_numpy(d).to(dev)
         oi = torch.empty((nq, k), dtype=torch.int32, device=dev); od = torch.empty((nq, k), dtype=torch.float32, device=dev)
-        _capi.check(lib.pann_merge_topk_dev(ti.data_ptr(), td.data_ptr(), W, nq, k, k, oi.data_ptr(), od.data_ptr(),
-                                            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _capi.check(lib.pann_merge_topk_dev(ti.data_ptr(), td.data_ptr(), W, nq, k, k, None, k, oi.data_ptr(), od.data_ptr(), st))
         torch.cuda.synchronize()
         ei, ed = D.merge_topk(ids, d, k)
         np.testing.assert_array_equal(oi.cpu().numpy().view(np.uint32), ei)
         np.testing.assert_array_equal(od.cpu().numpy(), ed)
+        # the packed form DeviceShardedIndex gathers: [W][nq][ids | distance bits], ids local to their shard + a base per list
+        base = (np.arange(W, dtype=np.uint32) * 1000)
+        loc = ids.copy(); used = ids != 0xFFFFFFFF
+        loc[used] = (ids - base[:, None, None])[used]
+        packed = np.concatenate([loc.view(np.int32), d.view(np.int32)], axis=2)
+        tp = torch.from_numpy(packed).to(dev); tb = torch.from_numpy(base.view(np.int32)).to(dev)
+        oi.fill_(0); od.fill_(0)
+        _capi.check(lib.pann_merge_topk_dev(tp.data_ptr(), tp.data_ptr() + 4 * k, W, nq, k, 2 * k, tb.data_ptr(), k, oi.data_ptr(),
+                                            od.data_ptr(), st))
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(oi.cpu().numpy().view(np.uint32), ei)
+        np.testing.assert_array_equal(od.cpu().numpy(), ed)
+
+
+def test_sharded_search_reads_the_status_word_and_relaunches_on_dropped_overflow(oracle):
+    """a _dev launch that reports PANN_STATUS_DROPPED_OVERFLOW has not produced valid lists; the sharded
+    path must grow the scratch and search again before it gathers (one rank here: the exchange is the identity).  Path-like
+    graph, cut = 1.0, k = 1: 600+ visited vertices are cut from a frontier that never fills (test_edge_cases_gpu.py)."""
+    import torch
+    from parlayann_amd import distributed as D
+    n = 1500
+    X = np.zeros((n, 8), np.float32); X[:, 0] = np.arange(n)
+    G = np.zeros((n, 5), np.uint32)
+    for i in range(n):
+        nb = [j for j in (i - 2, i - 1, i + 1, i + 2) if 0 <= j < n]
+        G[i, 0] = len(nb); G[i, 1:1 + len(nb)] = nb
+    Q = np.zeros((3, 8), np.float32); Q[:, 0] = [1499.0, 1400.5, 700.0]
+    o = oracle.batch_search(X, G, queries=Q, k=1, beam=16, cut=1.0, out_k=1)
+    assert o["visited_count"].max() > 600
+    sh = D.DeviceShardedIndex(X, 4, lambda ix: ix.set_graph(G))
+    assert sh.ix.dropped_capacity == 256
+    d_q = torch.from_numpy(Q.view(np.uint8).reshape(3, -1)).to(sh.dev)
+    oi, od = sh.search(d_q, 1, 16, cut=1.0, counters=True)
+    torch.cuda.synchronize()
+    assert sh.ix.dropped_capacity > 256 and sh.collectives == 1
+    np.testing.assert_array_equal(oi.cpu().numpy().view(np.uint32), o["ids"])
+    np.testing.assert_array_equal(od.cpu().numpy(), o["dists"])
+    np.testing.assert_array_equal(sh.last_counters[0].cpu().numpy().view(np.uint32), o["visited_count"])
+    sh.close()
