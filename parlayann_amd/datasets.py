@@ -68,3 +68,28 @@ def quantize_mips_int8(x, max_val=None):
     scale = np.float32(127.0) / np.float32(max_val)
     q = np.rint(x.astype(np.float32) * scale)
     return np.clip(q, -127, 127).astype(np.int8), max_val
+
+
+def sift_like_device(n, d, seed, device, dtype=np.float16, n_centers=256, rank=16, noise_scale=12.0, centers_seed=1234,
+                     chunk=1 << 18):
+    """`sift_like`'s mixture drawn ON THE GPU with torch's generator (plumbing: the 12.5M-point tables of bench.py's HBM-resident
+    leg and sharded-index mode would take minutes of numpy on the host) and copied back as a numpy array of `dtype`.  Same
+    geometry rule (cluster centres and low-rank bases from numpy's centers_seed stream, shared by base and queries), but NOT
+    the same points as `sift_like` for equal seeds.  Integer-valued in [0, 255]."""
+    import torch
+    crng = np.random.default_rng(centers_seed)
+    centers = torch.from_numpy(crng.normal(0.0, 22.0, size=(n_centers, d)).astype(np.float32)).to(device)
+    bases = torch.from_numpy(crng.normal(0.0, 9.0, size=(n_centers, rank, d)).astype(np.float32)).to(device)
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    tdt = {np.dtype(np.float16): torch.float16, np.dtype(np.float32): torch.float32, np.dtype(np.uint8): torch.uint8}[np.dtype(dtype)]
+    out = np.empty((n, d), dtype=dtype)
+    for s in range(0, n, chunk):
+        m = min(chunk, n - s)
+        cid = torch.randint(0, n_centers, (m,), generator=g, device=device)
+        coef = torch.randn((m, rank), generator=g, device=device)
+        x = centers[cid] + torch.bmm(coef.unsqueeze(1), bases[cid]).squeeze(1)
+        x += torch.randn((m, d), generator=g, device=device) * noise_scale
+        x = torch.clamp(torch.round(x + 100.0), 0, 255).to(tdt)
+        out[s:s + m] = x.cpu().numpy()
+    return out
