@@ -15,21 +15,18 @@ namespace parlayANN {
 template <typename Point, typename PointRange, typename indexType>
 void ANN(Graph<indexType>& G, long k, BuildParams& BP, PointRange& Query_Points, groundTruth<indexType> GT, char* res_file,
          bool graph_built, PointRange& Points) {
-  const auto t0 = std::chrono::steady_clock::now();
-  using findex = hcnng_index<Point, PointRange, indexType>;
-  double idx_time;
+  double idx_time = 0;
   if (!graph_built) {
-    findex I;
+    const auto t_build = std::chrono::steady_clock::now();
+    hcnng_index<Point, PointRange, indexType> I;
     I.seed = BP.seed;
     if (BP.host_tree) I.build_index_host_tree(G, Points, BP.num_clusters, BP.cluster_size, BP.MST_deg);
     else I.build_index(G, Points, BP.num_clusters, BP.cluster_size, BP.MST_deg);
-    idx_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    idx_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build).count();
     std::cout << "tree time: " << I.t_tree_s << " leaf knn time: " << I.t_leaf_s << " mst time: " << I.t_mst_s << std::endl;
-  } else { idx_time = 0; }
-  std::string name = "HCNNG";
-  std::string params = "Trees = " + std::to_string(BP.num_clusters);
-  auto [avg_deg, max_deg] = graph_stats_(G);
-  Graph_ G_(name, params, G.size(), avg_deg, max_deg, idx_time);
+  }
+  const auto [avg_deg, max_deg] = graph_stats_(G);
+  Graph_ G_("HCNNG", "Trees = " + std::to_string(BP.num_clusters), G.size(), avg_deg, max_deg, idx_time);
   G_.print();
   if (Query_Points.size() != 0) search_and_parse(G_, G, Points, Query_Points, GT, res_file, k, BP.verbose, BP.Q);
 }

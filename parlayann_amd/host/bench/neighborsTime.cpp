@@ -71,96 +71,162 @@ void run_plain(char* iFile, char* qFile, char* gFile, char* oFile, char* rFile, 
   timeNeighbors<Point, PR, uint>(G, Query_Points, k, BP, oFile, GT, rFile, graph_built, Points);
 }
 
+// ---- command line --------------------------------------------------------------------------------------------------
+// The flag NAMES, their defaults and their accepted ranges are the interface of the reference's `neighbors` binary
+// (bench/neighborsTime.C; tests/test_host_cpp_gpu.py pins them).  They live in ONE table; parsing, range checks and the
+// usage text are generated from it.
+namespace {
+
+enum class Kind { text, integer, real, toggle };
+
+struct FlagSpec {
+  const char* name;
+  Kind kind;
+  double fallback;        // value when the flag is absent (numeric kinds)
+  double lo, hi;          // accepted closed range (numeric kinds); outside -> usage + exit, like commandLine::badArgument
+  bool required;
+  const char* what;
+};
+
+constexpr double kAny = 9.0e18;
+
+const FlagSpec kFlags[] = {
+    // files and types
+    {"-base_path", Kind::text, 0, 0, 0, true, "base vectors (.bin: n, d, rows)"},
+    {"-query_path", Kind::text, 0, 0, 0, false, "query vectors"},
+    {"-gt_path", Kind::text, 0, 0, 0, false, "ground truth (n, k, ids, dists)"},
+    {"-graph_path", Kind::text, 0, 0, 0, false, "prebuilt graph to search"},
+    {"-graph_outfile", Kind::text, 0, 0, 0, false, "where to save the built graph"},
+    {"-res_path", Kind::text, 0, 0, 0, false, "csv of the search sweep"},
+    {"-data_type", Kind::text, 0, 0, 0, true, "uint8 | int8 | float"},
+    {"-dist_func", Kind::text, 0, 0, 0, true, "Euclidian | mips"},
+    // Vamana
+    {"-R", Kind::integer, 0, 0, kAny, false, "max degree"},
+    {"-L", Kind::integer, 0, 0, kAny, false, "build beam"},
+    {"-alpha", Kind::real, 1.0, -kAny, kAny, false, "prune slack"},
+    {"-num_passes", Kind::integer, 1, -kAny, kAny, false, "passes over the points"},
+    {"-two_pass", Kind::integer, 0, 0, 1, false, "1 = two passes"},
+    {"-single_batch", Kind::integer, 0, -kAny, kAny, false, "random start degree, one batch per pass"},
+    // HCNNG
+    {"-mst_deg", Kind::integer, 0, 0, kAny, false, "MST degree bound"},
+    {"-num_clusters", Kind::integer, 0, 0, kAny, false, "cluster trees"},
+    {"-cluster_size", Kind::integer, 0, 0, kAny, false, "leaf size"},
+    // search
+    {"-k", Kind::integer, 0, 0, 1000, false, "neighbours reported"},
+    {"-Q", Kind::integer, 0, -kAny, kAny, false, "single beam instead of the sweep"},
+    {"-rerank_factor", Kind::integer, 100, -kAny, kAny, false, "candidates re-scored per k"},
+    {"-delta", Kind::real, 0, 0, kAny, false, ""},
+    {"-radius", Kind::real, 0, -kAny, kAny, false, "range search radius"},
+    {"-radius_2", Kind::real, 0, -kAny, kAny, false, "expansion radius (default: -radius)"},
+    {"-trim", Kind::real, 0, -kAny, kAny, false, ""},
+    // transforms and modes
+    {"-quantize_bits", Kind::integer, 0, -kAny, kAny, false, "0 | 8"},
+    {"-quantize_mode", Kind::integer, 0, -kAny, kAny, false, "0 | 1"},
+    {"-verbose", Kind::toggle, 0, 0, 0, false, ""},
+    {"-normalize", Kind::toggle, 0, 0, 0, false, ""},
+    {"-self", Kind::toggle, 0, 0, 0, false, ""},
+    {"-range", Kind::toggle, 0, 0, 0, false, ""},
+    // this build's additions
+    {"-device", Kind::integer, 0, 0, 1023, false, "GPU ordinal"},
+    {"-seed", Kind::integer, 1, -kAny, kAny, false, "build seed"},
+    {"-use_existing", Kind::toggle, 0, 0, 0, false, "self range search seeded with out-neighbours"},
+    {"-host_tree", Kind::toggle, 0, 0, 0, false, "HCNNG cross-check path"},
+};
+
+std::string usage_text() {
+  std::string u;
+  for (const FlagSpec& f : kFlags) {
+    const char* arg = f.kind == Kind::text ? " <s>" : f.kind == Kind::integer ? " <n>" : f.kind == Kind::real ? " <x>" : "";
+    u += f.required ? std::string(f.name) + arg + " " : "[" + std::string(f.name) + arg + "] ";
+  }
+  return u;
+}
+
+// the parsed command line: every table row has a value
+class Flags {
+ public:
+  explicit Flags(commandLine& P) {
+    for (size_t i = 0; i < sizeof(kFlags) / sizeof(kFlags[0]); i++) {
+      const FlagSpec& f = kFlags[i];
+      Slot& v = slots_[i];
+      switch (f.kind) {
+        case Kind::text: v.s = P.getOptionValue(f.name); v.given = v.s != NULL; break;
+        case Kind::toggle: v.given = P.getOption(f.name); v.x = v.given ? 1 : 0; break;
+        case Kind::integer: v.given = P.getOptionValue(f.name) != NULL; v.x = (double)P.getOptionLongValue(f.name, (long)f.fallback); break;
+        case Kind::real: v.given = P.getOptionValue(f.name) != NULL; v.x = P.getOptionDoubleValue(f.name, f.fallback); break;
+      }
+      const bool numeric = f.kind == Kind::integer || f.kind == Kind::real;
+      if ((f.required && !v.given) || (numeric && (v.x < f.lo || v.x > f.hi))) P.badArgument();
+    }
+  }
+  char* text(const char* name) const { return at(name).s; }
+  long integer(const char* name) const { return (long)at(name).x; }
+  double real(const char* name) const { return at(name).x; }
+  bool on(const char* name) const { return at(name).x != 0; }
+  bool given(const char* name) const { return at(name).given; }
+
+ private:
+  struct Slot { char* s = NULL; double x = 0; bool given = false; };
+  Slot slots_[sizeof(kFlags) / sizeof(kFlags[0])];
+  const Slot& at(const char* name) const {
+    for (size_t i = 0; i < sizeof(kFlags) / sizeof(kFlags[0]); i++) if (std::strcmp(kFlags[i].name, name) == 0) return slots_[i];
+    std::cout << "internal error: flag " << name << " is not in the table" << std::endl;
+    abort();
+  }
+};
+
+[[noreturn]] void refuse(const std::string& why) {
+  std::cout << "Error: " << why << std::endl;
+  abort();
+}
+
+template <typename T>
+void run_typed(bool euclidian, const Flags& F, BuildParams& BP, groundTruth<uint>& GT) {
+  const bool is_float = std::is_same<T, float>::value;
+  const bool normalize = is_float && F.on("-normalize");
+  const int qbits = is_float ? (int)F.integer("-quantize_bits") : 0;
+  char* gFile = F.text("-graph_path");
+  if (euclidian)
+    run_plain<Euclidian_Point<T>>(F.text("-base_path"), F.text("-query_path"), gFile, F.text("-graph_outfile"), F.text("-res_path"),
+                                  BP.max_degree(), F.integer("-k"), BP, GT, gFile != NULL, normalize, qbits);
+  else
+    run_plain<Mips_Point<T>>(F.text("-base_path"), F.text("-query_path"), gFile, F.text("-graph_outfile"), F.text("-res_path"),
+                             BP.max_degree(), F.integer("-k"), BP, GT, gFile != NULL, normalize, qbits);
+}
+
+}  // namespace
+
 int main(int argc, char* argv[]) {
-  commandLine P(argc, argv,
-                "[-a <alpha>] [-d <delta>] [-R <deg>]"
-                "[-L <bm>] [-k <k> ]  [-gt_path <g>] [-query_path <qF>]"
-                "[-graph_path <gF>] [-graph_outfile <oF>] [-res_path <rF>]" "[-num_passes <np>]"
-                "[-memory_flag <algoOpt>] [-mst_deg <q>] [-num_clusters <nc>] [-cluster_size <cs>]"
-                "[-data_type <tp>] [-dist_func <df>] [-base_path <b>] [-device <d>] [-seed <s>] <inFile>");
+  commandLine P(argc, argv, usage_text());
+  const Flags F(P);
 
-  char* iFile = P.getOptionValue("-base_path");
-  char* oFile = P.getOptionValue("-graph_outfile");
-  char* gFile = P.getOptionValue("-graph_path");
-  char* qFile = P.getOptionValue("-query_path");
-  char* cFile = P.getOptionValue("-gt_path");
-  char* rFile = P.getOptionValue("-res_path");
-  char* vectype = P.getOptionValue("-data_type");
-  long Q = P.getOptionIntValue("-Q", 0);
-  long R = P.getOptionIntValue("-R", 0);
-  if (R < 0) P.badArgument();
-  long L = P.getOptionIntValue("-L", 0);
-  if (L < 0) P.badArgument();
-  long MST_deg = P.getOptionIntValue("-mst_deg", 0);
-  if (MST_deg < 0) P.badArgument();
-  long num_clusters = P.getOptionIntValue("-num_clusters", 0);
-  if (num_clusters < 0) P.badArgument();
-  long cluster_size = P.getOptionIntValue("-cluster_size", 0);
-  if (cluster_size < 0) P.badArgument();
-  double radius = P.getOptionDoubleValue("-radius", 0.0);
-  double radius_2 = P.getOptionDoubleValue("-radius_2", radius);
-  long k = P.getOptionIntValue("-k", 0);
-  if (k > 1000 || k < 0) P.badArgument();
-  double alpha = P.getOptionDoubleValue("-alpha", 1.0);
-  int num_passes = P.getOptionIntValue("-num_passes", 1);
-  int two_pass = P.getOptionIntValue("-two_pass", 0);
-  if (two_pass > 1 || two_pass < 0) P.badArgument();
-  if (two_pass == 1) num_passes = 2;
-  double delta = P.getOptionDoubleValue("-delta", 0);
-  if (delta < 0) P.badArgument();
-  char* dfc = P.getOptionValue("-dist_func");
-  int quantize = P.getOptionIntValue("-quantize_bits", 0);
-  int quantize_build = P.getOptionIntValue("-quantize_mode", 0);
-  bool verbose = P.getOption("-verbose");
-  bool normalize = P.getOption("-normalize");
-  double trim = P.getOptionDoubleValue("-trim", 0.0);  // not used
-  bool self = P.getOption("-self");
-  int rerank_factor = P.getOptionIntValue("-rerank_factor", 100);
-  bool range = P.getOption("-range");
-  int single_batch = P.getOptionIntValue("-single_batch", 0);
+  const std::string elem = F.text("-data_type"), metric = F.text("-dist_func");
+  if (elem != "uint8" && elem != "int8" && elem != "float") refuse("vector type not specified correctly, specify int8, uint8, or float");
+  if (metric != "Euclidian" && metric != "mips") refuse("specify distance type Euclidian or mips");
+  const long qbits = F.integer("-quantize_bits");
+  if (qbits != 0 && !(qbits == 8 && elem == "float")) refuse("-quantize_bits supports 8 with -data_type float (16 is not mirrored)");
 
-  if (!iFile || !dfc || !vectype) P.badArgument();
-  std::string df = std::string(dfc);
-  std::string tp = std::string(vectype);
-
-  BuildParams BP = BuildParams(R, L, alpha, num_passes, num_clusters, cluster_size, MST_deg, delta, verbose, quantize_build, radius,
-                               radius_2, self, range, single_batch, Q, trim, rerank_factor);
-  BP.seed = (uint64_t)P.getOptionLongValue("-seed", 1);
-  BP.use_existing = P.getOption("-use_existing");
-  BP.host_tree = P.getOption("-host_tree");
-  set_default_device(P.getOptionIntValue("-device", 0));
+  // BuildParams in the reference's constructor order (types.h:181-190)
+  const int passes = F.integer("-two_pass") == 1 ? 2 : (int)F.integer("-num_passes");
+  const double radius = F.real("-radius");
+  BuildParams BP(F.integer("-R"), F.integer("-L"), F.real("-alpha"), passes, F.integer("-num_clusters"), F.integer("-cluster_size"),
+                 F.integer("-mst_deg"), F.real("-delta"), F.on("-verbose"), (int)F.integer("-quantize_mode"), radius,
+                 F.given("-radius_2") ? F.real("-radius_2") : radius, F.on("-self"), F.on("-range"), (int)F.integer("-single_batch"),
+                 F.integer("-Q"), F.real("-trim"), (int)F.integer("-rerank_factor"));
+  BP.seed = (uint64_t)F.integer("-seed");
+  BP.use_existing = F.on("-use_existing");
+  BP.host_tree = F.on("-host_tree");
+  set_default_device((int)F.integer("-device"));
 #ifdef PANN_ALG_HCNNG
-  if (BP.alg_type != "HCNNG") { std::cout << "Error: HCNNG needs -num_clusters, -cluster_size and -mst_deg" << std::endl; abort(); }
+  if (BP.alg_type != "HCNNG") refuse("HCNNG needs -num_clusters, -cluster_size and -mst_deg");
 #else
-  if (BP.alg_type != "Vamana") { std::cout << "Error: Vamana needs -R, -L and -alpha" << std::endl; abort(); }
+  if (BP.alg_type != "Vamana") refuse("Vamana needs -R, -L and -alpha");
 #endif
-  long maxDeg = BP.max_degree();
 
-  if ((tp != "uint8") && (tp != "int8") && (tp != "float")) {
-    std::cout << "Error: vector type not specified correctly, specify int8, uint8, or float" << std::endl;
-    abort();
-  }
-  if (df != "Euclidian" && df != "mips") {
-    std::cout << "Error: specify distance type Euclidian or mips" << std::endl;
-    abort();
-  }
-  if (quantize != 0 && !(quantize == 8 && tp == "float")) {
-    std::cout << "Error: -quantize_bits supports 8 with -data_type float (16 is not mirrored)" << std::endl;
-    abort();
-  }
-
-  bool graph_built = (gFile != NULL);
-  groundTruth<uint> GT = groundTruth<uint>(cFile);
-
-  if (tp == "float") {
-    if (df == "Euclidian") run_plain<Euclidian_Point<float>>(iFile, qFile, gFile, oFile, rFile, maxDeg, k, BP, GT, graph_built, normalize, quantize);
-    else run_plain<Mips_Point<float>>(iFile, qFile, gFile, oFile, rFile, maxDeg, k, BP, GT, graph_built, normalize, quantize);
-  } else if (tp == "uint8") {
-    if (df == "Euclidian") run_plain<Euclidian_Point<uint8_t>>(iFile, qFile, gFile, oFile, rFile, maxDeg, k, BP, GT, graph_built, false, 0);
-    else run_plain<Mips_Point<uint8_t>>(iFile, qFile, gFile, oFile, rFile, maxDeg, k, BP, GT, graph_built, false, 0);
-  } else if (tp == "int8") {
-    if (df == "Euclidian") run_plain<Euclidian_Point<int8_t>>(iFile, qFile, gFile, oFile, rFile, maxDeg, k, BP, GT, graph_built, false, 0);
-    else run_plain<Mips_Point<int8_t>>(iFile, qFile, gFile, oFile, rFile, maxDeg, k, BP, GT, graph_built, false, 0);
-  }
+  groundTruth<uint> GT(F.text("-gt_path"));
+  const bool euclidian = metric == "Euclidian";
+  if (elem == "float") run_typed<float>(euclidian, F, BP, GT);
+  else if (elem == "uint8") run_typed<uint8_t>(euclidian, F, BP, GT);
+  else run_typed<int8_t>(euclidian, F, BP, GT);
   return 0;
 }

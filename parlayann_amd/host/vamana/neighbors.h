@@ -19,71 +19,74 @@
 
 namespace parlayANN {
 
+namespace vamana_driver {
+
+inline double seconds_since(std::chrono::steady_clock::time_point t) {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
+}
+
+// "-self -range" (:86-104): every base point range-searches from its own vertex -- ONE launch over all points.  same_as()
+// skips that start, so upstream reports 0 edges; BP.use_existing (this build's switch for the commented branch
+// beamSearch.h:260-262) seeds with the point's out-neighbours instead.  Prints the reference's report lines.
+template <typename PointRange, typename indexType>
+void self_range_report(Graph<indexType>& G, PointRange& Points, const BuildParams& BP, long build_num_distances) {
+  const auto t0 = std::chrono::steady_clock::now();
+  std::cout << "radius = " << BP.radius << " radius_2 = " << BP.radius_2 << std::endl;
+  const size_t n = Points.size();
+  const uint32_t per_point = BP.use_existing ? (uint32_t)G.max_degree() : 1;
+  std::vector<uint32_t> starts(n * (size_t)per_point, 0xFFFFFFFFu);
+  for (size_t v = 0; v < n; v++) {
+    if (!BP.use_existing) { starts[v] = (uint32_t)v; continue; }
+    auto nbrs = G[(indexType)v];
+    for (size_t j = 0; j < nbrs.size(); j++) starts[v * per_point + j] = nbrs[(indexType)j];
+  }
+  std::vector<long> found, cmps;
+  {
+    auto mirror = device_mirror(G, Points);
+    std::tie(found, cmps) = self_range_search(mirror.h(), n, starts, per_point, (float)BP.radius_2);
+  }
+  std::cout << "range search time: " << seconds_since(t0) << std::endl;
+  long edges = 0, range_num_distances = 0;
+  for (size_t v = 0; v < n; v++) { edges += found[v]; range_num_distances += cmps[v]; }
+  std::cout << "edges within range: " << edges << std::endl;
+  std::cout << "distance comparisons during build = " << build_num_distances << std::endl;
+  std::cout << "distance comparisons during range = " << range_num_distances << std::endl;
+}
+
+}  // namespace vamana_driver
+
+// The plugin's operator (:42-110).  Three steps: (1) build the graph on the build-precision points unless one was loaded;
+// (2) print the reference's graph report; (3) the query sweep, or the self range search.
 template <typename PointRange, typename QPointRange, typename QQPointRange, typename indexType>
 void ANN_Quantized(Graph<indexType>& G, long k, BuildParams& BP, PointRange& Query_Points, QPointRange& Q_Query_Points,
                    QQPointRange& QQ_Query_Points, groundTruth<indexType> GT, char* res_file, bool graph_built, PointRange& Points,
                    QPointRange& Q_Points, QQPointRange& QQ_Points) {
-  const auto t0 = std::chrono::steady_clock::now();
-  bool verbose = BP.verbose;
-  using findex = knn_index<QPointRange, QQPointRange, indexType>;
-  findex I(BP);
-  I.seed = BP.seed;
-  indexType start_point;
-  double idx_time;
   stats<unsigned int> BuildStats(G.size());
-  if (graph_built) {
-    idx_time = 0;
-    start_point = 0;
-  } else {
+  indexType start_point = 0;
+  double idx_time = 0;
+  if (!graph_built) {
+    const auto t_build = std::chrono::steady_clock::now();
+    knn_index<QPointRange, QQPointRange, indexType> I(BP);
+    I.seed = BP.seed;
     I.build_index(G, Q_Points, QQ_Points, BuildStats);
     start_point = I.get_start();
-    idx_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    idx_time = vamana_driver::seconds_since(t_build);
   }
   std::cout << "start index = " << start_point << std::endl;
 
-  std::string name = "Vamana";
-  std::string params = "R = " + std::to_string(BP.R) + ", L = " + std::to_string(BP.L);
-  auto [avg_deg, max_deg] = graph_stats_(G);
-  auto vv = BuildStats.visited_stats();
-  std::cout << "Average visited: " << vv[0] << ", Tail visited: " << vv[1] << std::endl;
-  Graph_ G_(name, params, G.size(), avg_deg, max_deg, idx_time);
+  const auto visited = BuildStats.visited_stats();
+  std::cout << "Average visited: " << visited[0] << ", Tail visited: " << visited[1] << std::endl;
+  const auto [avg_deg, max_deg] = graph_stats_(G);
+  Graph_ G_("Vamana", "R = " + std::to_string(BP.R) + ", L = " + std::to_string(BP.L), G.size(), avg_deg, max_deg, idx_time);
   G_.print();
-
-  long build_num_distances = 0;
-  for (auto x : BuildStats.distances) build_num_distances += (long)x;
 
   if (Query_Points.size() != 0) {
     search_and_parse(G_, G, Points, Query_Points, Q_Points, Q_Query_Points, QQ_Points, QQ_Query_Points, GT, res_file, k, false,
-                     start_point, verbose, BP.Q, BP.rerank_factor);
-  } else if (BP.self) {
-    if (BP.range) {
-      // :86-104: every base point range-searches from its own vertex -- ONE launch over all points.  same_as() skips
-      // that start, so upstream reports 0 edges; BP.use_existing (this build's switch for the commented branch
-      // beamSearch.h:260-262) seeds with the point's out-neighbours instead.
-      const auto tr = std::chrono::steady_clock::now();
-      double radius = BP.radius;
-      double radius_2 = BP.radius_2;
-      std::cout << "radius = " << radius << " radius_2 = " << radius_2 << std::endl;
-      const size_t n = Points.size();
-      const uint32_t ns = BP.use_existing ? (uint32_t)G.max_degree() : 1;
-      std::vector<uint32_t> starts(n * (size_t)ns, 0xFFFFFFFFu);
-      for (size_t i = 0; i < n; i++) {
-        if (!BP.use_existing) { starts[i] = (uint32_t)i; continue; }
-        auto row = G[(indexType)i];
-        for (size_t j = 0; j < row.size(); j++) starts[i * ns + j] = row[(indexType)j];
-      }
-      std::vector<long> counts, distance_comps;
-      {
-        auto L = device_mirror(G, Points);
-        std::tie(counts, distance_comps) = self_range_search(L.h(), n, starts, ns, (float)radius_2);
-      }
-      std::cout << "range search time: " << std::chrono::duration<double>(std::chrono::steady_clock::now() - tr).count() << std::endl;
-      long range_num_distances = 0, edges = 0;
-      for (size_t i = 0; i < n; i++) { edges += counts[i]; range_num_distances += distance_comps[i]; }
-      std::cout << "edges within range: " << edges << std::endl;
-      std::cout << "distance comparisons during build = " << build_num_distances << std::endl;
-      std::cout << "distance comparisons during range = " << range_num_distances << std::endl;
-    }
+                     start_point, BP.verbose, BP.Q, BP.rerank_factor);
+  } else if (BP.self && BP.range) {
+    long build_num_distances = 0;
+    for (auto x : BuildStats.distances) build_num_distances += (long)x;
+    vamana_driver::self_range_report(G, Points, BP, build_num_distances);
   }
 }
 
