@@ -304,6 +304,18 @@ __device__ __forceinline__ void dist_accum_exact(float& acc, const uint4& a, con
 template <int DT> constexpr bool is_float_dt() { return DT == PANN_F32 || DT == PANN_F16 || DT == PANN_BF16; }
 
 
+// 16 bytes of a gathered base-point row.  -DPANN_NT_ROWS (A/B builds): non-temporal, so the streamed rows do not displace
+// the per-query filter tables from the XCD's L2.
+__device__ __forceinline__ uint4 row_load16(const uint8_t* p) {
+#ifdef PANN_NT_ROWS
+  typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
+  const u32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+#else
+  return *reinterpret_cast<const uint4*>(p);
+#endif
+}
+
 // one iteration of the gather: U groups of G = 64/LPC candidates starting at Pl[s0]
 template <int DT, int METRIC, int LPC, bool NCH1, int U, typename Emit>
 __device__ __forceinline__ void gather_iter(const PointsView& PV, const QReg<DT>& qreg, const uint4* qlds,
@@ -319,7 +331,7 @@ __device__ __forceinline__ void gather_iter(const PointsView& PV, const QReg<DT>
     uint4 v[U];
 #pragma unroll
     for (int u = 0; u < U; u++)
-      v[u] = *reinterpret_cast<const uint4*>(PV.points + (uint64_t)ids[u] * PV.pstride + sub * 16);
+      v[u] = row_load16(PV.points + (uint64_t)ids[u] * PV.pstride + sub * 16);
 #pragma unroll
     for (int u = 0; u < U; u++) { acc[u].clear(); dist_accum<DT, METRIC>(acc[u], v[u], qreg); }
   } else {
@@ -338,7 +350,7 @@ __device__ __forceinline__ void gather_iter(const PointsView& PV, const QReg<DT>
       for (int cb = 0; cb < CB; cb++) {
         const uint32_t chx = min(ch0 + cb, PV.nch - 1);
 #pragma unroll
-        for (int u = 0; u < U; u++) v[cb][u] = *reinterpret_cast<const uint4*>(rp[u] + chx * (LPC * 16));
+        for (int u = 0; u < U; u++) v[cb][u] = row_load16(rp[u] + chx * (LPC * 16));
       }
 #pragma unroll
       for (int cb = 0; cb < CB; cb++) {
