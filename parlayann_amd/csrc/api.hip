@@ -438,27 +438,63 @@ static int batch_search_host(pann_index* idx, const void* queries, const uint32_
 
   d.status = nullptr;   // read from the workspace below
   uint32_t status = 0;
+  // The "dropped" scratch is nq * dcap * 8 bytes.  When a launch reports that it was too small the list is grown (x8, up to
+  // min(limit, n): a query drops at most one entry per visited vertex) and the batch runs again; a grown list that would take
+  // more than kDropBudget for the whole batch makes the batch run in ranges of queries instead, and the handle keeps at most
+  // kDropKeep entries per query for later calls (10K queries x 2048 x 8 B = 160 MB), not the worst case of one odd batch.
+  constexpr uint64_t kDropBudget = 1ull << 30;
+  constexpr uint32_t kDropKeep = 2048;
+  const uint64_t dneed = (uint64_t)std::min<int64_t>(std::max<int64_t>(qp->limit, 1), (int64_t)ix.n);
+  uint32_t dcap = idx->dcap;
+  bool results_home = false;        // the packed outputs already sit in pin_out
   for (;;) {
-    SearchArgs a;
-    a.queries = (const uint8_t*)d_q; a.qstride = q_stride_bytes; a.query_ids = d_qid;
-    a.nq = nq; a.starts = d_starts; a.nstarts = nstarts; a.starts_per_query = per_query;
-    a.k = qp->k; a.beam = qp->beam; a.limit = qp->limit; a.degree_limit = qp->degree_limit; a.cut = qp->cut;
-    a.dcap = idx->dcap;
-    a.out = d;
-    if (int rc = idx->ws.ensure(search_workspace_bytes(idx->ix, a))) return rc;
-    if (int rc = launch_beam_search(idx->ix, a, idx->ws.buf, idx->ws.bytes, st)) return rc;
-    // the status word travels with the results
-    PANN_HIP(hipMemcpyAsync((uint8_t*)idx->stage[4].p + out_bytes, (uint8_t*)idx->ws.buf + 64, 4, hipMemcpyDeviceToDevice, st));
-    PANN_HIP(hipMemcpyAsync(idx->pin_out.p, idx->stage[4].p, out_bytes + 4, hipMemcpyDeviceToHost, st));
-    PANN_HIP(hipStreamSynchronize(st));
-    std::memcpy(&status, (uint8_t*)idx->pin_out.p + out_bytes, 4);
+    const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(nq, kDropBudget / ((uint64_t)std::max<uint32_t>(dcap, 64) * 8)));
+    status = 0;
+    for (uint64_t q0 = 0; q0 < nq; q0 += chunk) {
+      const uint64_t cnt = std::min(chunk, nq - q0);
+      SearchArgs a;
+      a.queries = d_q ? (const uint8_t*)d_q + q0 * q_stride_bytes : nullptr; a.qstride = q_stride_bytes;
+      a.query_ids = d_qid ? d_qid + q0 : nullptr;
+      a.nq = cnt; a.starts = per_query ? d_starts + q0 * nstarts : d_starts; a.nstarts = nstarts; a.starts_per_query = per_query;
+      a.k = qp->k; a.beam = qp->beam; a.limit = qp->limit; a.degree_limit = qp->degree_limit; a.cut = qp->cut;
+      a.dcap = dcap;
+      a.out = d;
+      if (a.out.ids) a.out.ids += q0 * ok;
+      if (a.out.dists) a.out.dists += q0 * ok;
+      if (a.out.frontier_size) a.out.frontier_size += q0;
+      if (a.out.visited_count) a.out.visited_count += q0;
+      if (a.out.dist_cmps) a.out.dist_cmps += q0;
+      if (a.out.degree_sum) a.out.degree_sum += q0;
+      if (a.out.visited_ids) a.out.visited_ids += q0 * vc;
+      if (a.out.visited_dists) a.out.visited_dists += q0 * vc;
+      if (int rc = idx->ws.ensure(search_workspace_bytes(idx->ix, a))) return rc;
+      if (int rc = launch_beam_search(idx->ix, a, idx->ws.buf, idx->ws.bytes, st)) return rc;
+      uint32_t st_word = 0;      // the launch's status word (the next launch clears it)
+      if (cnt == nq) {           // the whole batch in one launch (the normal case): the word travels with the results, ONE transfer
+        PANN_HIP(hipMemcpyAsync((uint8_t*)idx->stage[4].p + out_bytes, (uint8_t*)idx->ws.buf + 64, 4, hipMemcpyDeviceToDevice, st));
+        PANN_HIP(hipMemcpyAsync(idx->pin_out.p, idx->stage[4].p, out_bytes + 4, hipMemcpyDeviceToHost, st));
+        PANN_HIP(hipStreamSynchronize(st));
+        std::memcpy(&st_word, (uint8_t*)idx->pin_out.p + out_bytes, 4);
+        results_home = true;
+      } else {
+        PANN_HIP(hipMemcpyAsync(&st_word, (uint8_t*)idx->ws.buf + 64, 4, hipMemcpyDeviceToHost, st));
+        PANN_HIP(hipStreamSynchronize(st));
+        results_home = false;
+      }
+      status |= st_word;
+      if (status & PANN_STATUS_DROPPED_OVERFLOW) break;
+    }
     if (!(status & PANN_STATUS_DROPPED_OVERFLOW)) break;
-    // The reference has no such list (its `visited` vector grows as needed, beamSearch.h:80,113): grow ours and run
-    // the batch again.  A query can drop at most one entry per visited vertex, so min(limit, n) entries always suffice.
-    const uint64_t need = (uint64_t)std::min<int64_t>(std::max<int64_t>(qp->limit, 1), (int64_t)ix.n);
-    if ((uint64_t)idx->dcap >= need) { set_error("pann_batch_search: internal dropped-list overflow"); return PANN_ERR_OVERFLOW; }
-    idx->dcap = (uint32_t)std::min<uint64_t>((uint64_t)idx->dcap * 8, (need + 63) / 64 * 64);
+    // The reference has no such list (its `visited` vector grows as needed, beamSearch.h:80,113): grow ours and run the batch again.
+    if ((uint64_t)dcap >= dneed) { set_error("pann_batch_search: internal dropped-list overflow"); return PANN_ERR_OVERFLOW; }
+    dcap = (uint32_t)std::min<uint64_t>((uint64_t)dcap * 8, (dneed + 63) / 64 * 64);
   }
+  idx->dcap = std::max(idx->dcap, std::min(dcap, kDropKeep));
+  if (!results_home) {
+    PANN_HIP(hipMemcpyAsync(idx->pin_out.p, idx->stage[4].p, out_bytes, hipMemcpyDeviceToHost, st));
+    PANN_HIP(hipStreamSynchronize(st));
+  }
+  if (idx->ws.bytes > (2ull << 30)) idx->ws.release();          // a one-off worst-case scratch is not kept on the handle
   for (auto& x : pc) if (x.bytes) std::memcpy(x.host, (uint8_t*)idx->pin_out.p + x.off, x.bytes);
   if (out->status) *out->status = status;
   if (status & PANN_STATUS_VISITED_OVERFLOW) { set_error("pann_batch_search: visited list longer than visited_cap"); return PANN_ERR_OVERFLOW; }

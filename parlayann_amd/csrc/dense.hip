@@ -612,7 +612,14 @@ __global__ void __launch_bounds__(256) dense_topk_mfma_f16_kernel(DenseArgs A) {
 //     na/64 workgroups that stream the same rows.
 // LDS is 36 KB per workgroup, so 2-3 workgroups share a CU (register-bound).  Results are the same sets as the
 // kernel above: a row's list ends as the m smallest (distance, id) keys of its piece, whatever the insert order.
-constexpr int GT_BT_BYTES = DT_B * DT_BSTRIDE;
+// B tile of the ground-truth kernels: 64 rows of 256 bytes, NO padding, the 16-byte slot of a row XOR-swizzled with the row
+// number: byte (row, off) lives at row * 256 + (off ^ ((row & 15) << 4)).  ds_read_b128 serves a wave in four groups of 16
+// lanes that mix two quarters ({0-3,12-15,20-27}, ...; MI355X_MICROARCH.md, LDS): with the padded rows of the kernels above
+// (272-byte stride) the MFMA fragment read -- lane = row (lane & 15), slot 4 ks + (lane >> 4) -- put two lanes of a group on one
+// bank (35 % of the LDS cycles of round 2 were conflict cycles); with the swizzle every group reads 16 different slots.
+constexpr int GT_BSTRIDE = DT_SEG;
+constexpr int GT_BT_BYTES = DT_B * GT_BSTRIDE;
+__device__ __forceinline__ uint32_t gt_swz(uint32_t row, uint32_t off) { return row * GT_BSTRIDE + (off ^ ((row & 15u) << 4)); }
 constexpr uint32_t GT_TAU_PERIOD = 8;      // tiles between two looks at what the other pieces of a row have published
 
 template <bool BF>
@@ -678,6 +685,9 @@ __device__ __forceinline__ void gt_lds_barrier() { asm volatile("s_waitcnt lgkmc
 
 // selection state of a wave in the ground-truth / leaf kernels: lists, float thresholds, what was published.
 // NR registers of 16 places per row: 8 (m <= 128, ground truth) or 1 (m <= 16: HCNNG leaves, small-k ground truth).
+// survivor queues of the queued selection (gt_select_queued below): 16 rows per wave, GT_QCAP keys each
+constexpr uint32_t GT_QCAP = 64;       // >= 4 x 16: what one tile can offer a row
+constexpr size_t GT_QUEUE_BYTES = 4 * (size_t)DT_AW * GT_QCAP * 8;      // per workgroup: 32 KB
 template <int NR>
 struct GtSel {
   uint64_t R[4][NR];     // R[r] = row 4q + r, right-aligned in 16*NR places (the leading ones hold key 0, which nothing displaces):
@@ -685,6 +695,7 @@ struct GtSel {
   float tauf[4];         // float copy of the row's threshold (min of its own m-th best and the bound shared by the pieces)
   bool rowok[4];
   uint32_t pub[4];       // last value published per row (lane 0 of the quarter)
+  uint32_t cnt[4];       // keys waiting in the row's LDS queue (gt_select_queued)
 };
 template <int NR>
 __device__ __forceinline__ void gt_sel_init(GtSel<NR>& S, uint32_t m, uint32_t row0, uint32_t na_tile, int lane) {
@@ -695,6 +706,7 @@ __device__ __forceinline__ void gt_sel_init(GtSel<NR>& S, uint32_t m, uint32_t r
     S.rowok[r] = row0 + r < na_tile;
     S.tauf[r] = S.rowok[r] ? __builtin_inff() : -__builtin_inff();        // a padding row accepts nothing
     S.pub[r] = 0xFFFFFFFFu;
+    S.cnt[r] = 0;
   }
 }
 // Every piece of a row publishes its ceil(m / nsplit)-th best.  The largest of those bounds the final m-th best from above
@@ -783,6 +795,106 @@ __device__ __forceinline__ void gt_select(GtSel<NR>& S, const float (&dist)[4][4
     }
   }
 }
+// ---- queued selection (round 3).  gt_select above inserts a survivor the moment it appears: 0.84 insert rounds per wave-tile
+// at k = 100, each a ~180-instruction round that serves 1.3 of the 4 quarters on average, and the wave that inserts makes the
+// other three wait at the tile barrier.  Here a survivor of the float test is only APPENDED to its row's queue in LDS (GT_QCAP
+// keys per row, 16 rows per wave); when an append would not fit, the wave empties all its queues: for r = 0..3 the four
+// quarters insert key i of "their" row r together (a quarter that has run out inserts KEY_INF, a no-op), so a round is one
+// broadcast LDS read + the shift/max chain and serves up to four rows, and a wave-tile without a survivor costs the compares and
+// nothing else.  The thresholds move only at a flush, so more candidates are queued than the immediate form inserts; a queued
+// key that no longer beats its row's m-th best falls out of the chain unchanged.  Same result: every candidate at or below the
+// (stale, hence larger) threshold is offered to the exact 64-bit insert.
+
+template <int NR>
+__device__ __forceinline__ void gt_flush(GtSel<NR>& S, const uint64_t* Qw /* this wave's [16][GT_QCAP] */, uint32_t pplace,
+                                         uint32_t* gtau_mine, uint32_t nsplit, int lane) {
+  const int q = lane >> 4;
+  wave_lds_sync();                                               // the appends of this wave are visible to its reads
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const uint32_t c0 = __builtin_amdgcn_readlane(S.cnt[r], 0), c1 = __builtin_amdgcn_readlane(S.cnt[r], 16);
+    const uint32_t c2 = __builtin_amdgcn_readlane(S.cnt[r], 32), c3 = __builtin_amdgcn_readlane(S.cnt[r], 48);
+    const uint32_t nmax = max(max(c0, c1), max(c2, c3));
+    if (nmax == 0) continue;
+    const uint64_t* Qr = Qw + (size_t)(q * 4 + r) * GT_QCAP;
+    for (uint32_t i = 0; i < nmax; i++) {
+      const uint64_t x = i < S.cnt[r] ? Qr[i] : KEY_INF;
+      GT_COUNT(2, 1);
+      gt_quarter_insert<NR>(S.R[r], x);
+    }
+    S.cnt[r] = 0;
+    // the row's m-th best has tightened: refresh the float threshold
+    uint32_t th = 0;
+#pragma unroll
+    for (int C = 0; C < 4; C++) {
+      const uint32_t h = __builtin_amdgcn_readlane((uint32_t)(S.R[r][NR - 1] >> 32), 16 * C + 15);
+      if (q == C) th = h;
+    }
+    const float nt = th == 0xFFFFFFFFu ? __builtin_inff() : ord2f(th);
+    S.tauf[r] = !S.rowok[r] ? -__builtin_inff() : fminf(S.tauf[r], nt);
+    // this piece's share-th best (place pplace of the list): publish it when it improved
+    uint32_t ph = (uint32_t)(S.R[r][0] >> 32);
+#pragma unroll
+    for (int j = 1; j < NR; j++) ph = (pplace >> 4) == (uint32_t)j ? (uint32_t)(S.R[r][j] >> 32) : ph;
+    uint32_t pv = 0;
+#pragma unroll
+    for (int C = 0; C < 4; C++) {
+      const uint32_t h = __builtin_amdgcn_readlane(ph, 16 * C + (int)(pplace & 15));
+      if (q == C) pv = h;
+    }
+    if ((lane & 15) == 0 && S.rowok[r] && pv < S.pub[r]) {
+      S.pub[r] = pv;
+      __hip_atomic_store(gtau_mine + (size_t)r * nsplit, pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  wave_lds_sync();                                               // the queue may be written again
+}
+
+// Pass 1 appends every (row r, column block t) group of offers that fits; a group that does not is left for pass 2, after ONE
+// flush (a single call site: inlined into each of the 16 groups the flush made the tile loop a 13 000-instruction body; a real
+// loop around one copy of the append code made hipcc copy the lists at every back edge and cost 2 ms).  After a flush the queues
+// are empty and a row receives at most 4 x 16 keys from one tile, so pass 2 always fits (GT_QCAP >= 64).
+template <int NR>
+__device__ __forceinline__ void gt_select_queued(GtSel<NR>& S, const float (&dist)[4][4], const uint32_t (&bid)[4], const uint32_t (&skip)[4],
+                                                 uint32_t pplace, uint32_t* gtau_mine, uint32_t nsplit, uint64_t* Qw, int lane) {
+  const int q = lane >> 4;
+  bool any = false;
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+#pragma unroll
+    for (int t = 0; t < 4; t++) any = any || (dist[r][t] <= S.tauf[r]);
+  if (!__any(any)) return;
+  const uint32_t below = (1u << (lane & 15)) - 1u;
+  uint32_t left = 0;                                             // wave-uniform: bit 4r + t
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const bool p = dist[r][t] <= S.tauf[r] && bid[t] != SENTINEL && bid[t] != skip[r];
+      const uint64_t m = __ballot(p);
+      if (m == 0ull) continue;                                   // wave-uniform
+      const uint32_t f = (uint32_t)(m >> (16 * q)) & 0xFFFFu;    // the offers of my quarter
+      const uint32_t n = __popc(f);
+      if (__any(S.cnt[r] + n > GT_QCAP)) { left |= 1u << (4 * r + t); continue; }
+      if (p) Qw[(size_t)(q * 4 + r) * GT_QCAP + S.cnt[r] + __popc(f & below)] = make_key(dist[r][t], bid[t]);
+      S.cnt[r] += n;
+    }
+  }
+  if (left == 0) return;
+  gt_flush<NR>(S, Qw, pplace, gtau_mine, nsplit, lane);
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      if (!((left >> (4 * r + t)) & 1u)) continue;
+      const bool p = dist[r][t] <= S.tauf[r] && bid[t] != SENTINEL && bid[t] != skip[r];      // (the threshold has just tightened)
+      const uint32_t f = (uint32_t)(__ballot(p) >> (16 * q)) & 0xFFFFu;
+      if (p) Qw[(size_t)(q * 4 + r) * GT_QCAP + S.cnt[r] + __popc(f & below)] = make_key(dist[r][t], bid[t]);
+      S.cnt[r] += __popc(f);
+    }
+  }
+}
+
 // this piece's lists -> partial[row][piece][0..m): place p of a list is entry p - (16*NR - m)
 template <int NR>
 __device__ __forceinline__ void gt_sel_write(const GtSel<NR>& S, uint64_t* partial_row0 /* [row 4q of this wave][this piece][0] */,
@@ -804,10 +916,11 @@ __device__ __forceinline__ void gt_sel_write(const GtSel<NR>& S, uint64_t* parti
 template <int METRIC, bool BF, int NR>
 __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, const float* __restrict__ bnorm, uint32_t* gtau) {
   extern __shared__ __align__(16) uint8_t smem[];
-  uint8_t* Bt0 = smem;                                                    // [2][64][DT_BSTRIDE]
+  uint8_t* Bt0 = smem;                                                    // [2][64][GT_BSTRIDE], slots swizzled (gt_swz)
   float2* Bm = reinterpret_cast<float2*>(smem + 2 * GT_BT_BYTES);         // [2][64] (|b|^2, id bits)
   float* An = reinterpret_cast<float*>(Bm + 2 * DT_B);                    // [64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4;
+  uint64_t* Qw = reinterpret_cast<uint64_t*>(An + DT_A) + (size_t)wave * DT_AW * GT_QCAP;   // this wave's survivor queues [16][GT_QCAP]
   const uint64_t a0 = (uint64_t)blockIdx.x * DT_A;
   const uint32_t na_tile = (uint32_t)min((uint64_t)DT_A, A.na - a0);
   const uint64_t per = ((A.nb + A.nsplit - 1) / A.nsplit + DT_B - 1) / DT_B * DT_B;
@@ -836,6 +949,13 @@ __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, cons
 #pragma unroll
   for (int ks = 0; ks < 4; ks++) af[ks] = a_load(wave * DT_AW + (lane & 15), ks * 64 + q * 16);
 
+  // The queue pays where an insert is long: k > 16 (NR = 8, an 80-instruction shift chain: 12.9 -> 11.0 ms at k = 100).  At
+  // k <= 16 (NR = 1) an insert is one shift + max step, cheaper than a trip through the queue (6.8 vs 7.5 ms at k = 10).
+#ifdef PANN_GT_IMMEDIATE
+  constexpr bool QUEUED = false;
+#else
+  constexpr bool QUEUED = NR > 1;
+#endif
   GtSel<NR> S;
   gt_sel_init<NR>(S, A.m, (uint32_t)(wave * DT_AW + q * 4), na_tile, lane);
   const uint32_t skip[4] = {SENTINEL, SENTINEL, SENTINEL, SENTINEL};
@@ -869,11 +989,11 @@ __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, cons
   };
   auto store_pre = [&](int buf, uint64_t bt) {
     if (cvalid) {
-      uint8_t* dst = Bt0 + buf * GT_BT_BYTES + (size_t)r0 * DT_BSTRIDE + c * 16;
+      uint8_t* dst = Bt0 + buf * GT_BT_BYTES + gt_swz((uint32_t)r0, (uint32_t)c * 16u);      // rows r0 + 16 k share r0's swizzle
       *reinterpret_cast<uint4*>(dst) = pre0;
-      *reinterpret_cast<uint4*>(dst + 16 * DT_BSTRIDE) = pre1;
-      *reinterpret_cast<uint4*>(dst + 32 * DT_BSTRIDE) = pre2;
-      *reinterpret_cast<uint4*>(dst + 48 * DT_BSTRIDE) = pre3;
+      *reinterpret_cast<uint4*>(dst + 16 * GT_BSTRIDE) = pre1;
+      *reinterpret_cast<uint4*>(dst + 32 * GT_BSTRIDE) = pre2;
+      *reinterpret_cast<uint4*>(dst + 48 * GT_BSTRIDE) = pre3;
     }
     if (tid < DT_B)
       Bm[buf * DT_B + tid] = make_float2(pn, __uint_as_float(bt + tid < be ? (uint32_t)(bt + tid) : SENTINEL));
@@ -881,7 +1001,7 @@ __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, cons
   if (!cvalid) {
 #pragma unroll
     for (int k = 0; k < 8; k++)
-      *reinterpret_cast<uint4*>(Bt0 + (k >> 2) * GT_BT_BYTES + (size_t)(r0 + 16 * (k & 3)) * DT_BSTRIDE + c * 16) = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(Bt0 + (k >> 2) * GT_BT_BYTES + gt_swz((uint32_t)(r0 + 16 * (k & 3)), (uint32_t)c * 16u)) = make_uint4(0, 0, 0, 0);
   }
   if (ntile > 0) {           // (an empty piece issues no loads: last_row is meaningless there)
     load_pre(bs); store_pre(0, bs);
@@ -912,14 +1032,14 @@ __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, cons
         mf_bf8 a8; __builtin_memcpy(&a8, &af[ks], 16);
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-          const mf_bf8 b8 = *reinterpret_cast<const mf_bf8*>(Bt + (size_t)(t * 16 + (lane & 15)) * DT_BSTRIDE + koff);
+          const mf_bf8 b8 = *reinterpret_cast<const mf_bf8*>(Bt + gt_swz((uint32_t)(t * 16 + (lane & 15)), koff));
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, acc[t], 0, 0, 0);
         }
       } else {
         mf_half8 a8; __builtin_memcpy(&a8, &af[ks], 16);
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-          const mf_half8 b8 = *reinterpret_cast<const mf_half8*>(Bt + (size_t)(t * 16 + (lane & 15)) * DT_BSTRIDE + koff);
+          const mf_half8 b8 = *reinterpret_cast<const mf_half8*>(Bt + gt_swz((uint32_t)(t * 16 + (lane & 15)), koff));
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, b8, acc[t], 0, 0, 0);
         }
       }
@@ -928,19 +1048,21 @@ __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, cons
     float bn[4]; uint32_t bid[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) { const float2 m2 = Bm[buf * DT_B + t * 16 + (lane & 15)]; bn[t] = m2.x; bid[t] = __float_as_uint(m2.y); }
+    GT_COUNT(0, 1);
+    auto distf = [&](int r, int t) -> float {
+      if constexpr (METRIC == PANN_L2) return (an[r] + bn[t]) - 2.0f * acc[t][r];
+      else return -acc[t][r];
+    };
     float dist[4][4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < 4; r++)
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        if constexpr (METRIC == PANN_L2) dist[r][t] = (an[r] + bn[t]) - 2.0f * acc[t][r];
-        else dist[r][t] = -acc[t][r];
-      }
-    }
-    GT_COUNT(0, 1);
-    gt_select<NR>(S, dist, bid, skip, pplace, gtau_mine, A.nsplit, lane);
+      for (int t = 0; t < 4; t++) dist[r][t] = distf(r, t);
+    if constexpr (QUEUED) gt_select_queued<NR>(S, dist, bid, skip, pplace, gtau_mine, A.nsplit, Qw, lane);
+    else gt_select<NR>(S, dist, bid, skip, pplace, gtau_mine, A.nsplit, lane);
     gt_lds_barrier();
   }
+  if constexpr (QUEUED) gt_flush<NR>(S, Qw, pplace, gtau_mine, A.nsplit, lane);
   gt_sel_write<NR>(S, A.partial + ((a0 + wave * DT_AW + q * 4) * A.nsplit + blockIdx.y) * A.m, A.m, A.nsplit, lane);
 }
 
@@ -1010,7 +1132,7 @@ __global__ void __launch_bounds__(256, 2) dense_gt_valu_kernel(DenseArgs A, cons
   extern __shared__ __align__(16) uint8_t smem[];
   const uint32_t nseg = (A.pstride + DT_SEG - 1) / DT_SEG;              // 1 or 2 (the launcher checks)
   const uint32_t astride = nseg * DT_SEG + 16;
-  uint8_t* Bt0 = smem;                                                    // [2][64][DT_BSTRIDE]
+  uint8_t* Bt0 = smem;                                                    // [2][64][GT_BSTRIDE], slots swizzled (gt_swz)
   float2* Bm = reinterpret_cast<float2*>(smem + 2 * GT_BT_BYTES);         // [2][64] (|b|^2 bits, id bits)
   int* An = reinterpret_cast<int*>(Bm + 2 * DT_B);                        // [64] |a|^2 (one-byte types, L2)
   uint8_t* At = reinterpret_cast<uint8_t*>(An + DT_A);                    // [64][astride]
@@ -1082,11 +1204,11 @@ __global__ void __launch_bounds__(256, 2) dense_gt_valu_kernel(DenseArgs A, cons
     const uint32_t bt = unit_bt(u);
     const int buf = (int)(u & 1);
     if ((nseg == 2 && (u & 1)) ? cv1 : cv0) {
-      uint8_t* dst = Bt0 + buf * GT_BT_BYTES + (size_t)r0 * DT_BSTRIDE + c * 16;
+      uint8_t* dst = Bt0 + buf * GT_BT_BYTES + gt_swz((uint32_t)r0, (uint32_t)c * 16u);      // rows r0 + 16 k share r0's swizzle
       *reinterpret_cast<uint4*>(dst) = pre0;
-      *reinterpret_cast<uint4*>(dst + 16 * DT_BSTRIDE) = pre1;
-      *reinterpret_cast<uint4*>(dst + 32 * DT_BSTRIDE) = pre2;
-      *reinterpret_cast<uint4*>(dst + 48 * DT_BSTRIDE) = pre3;
+      *reinterpret_cast<uint4*>(dst + 16 * GT_BSTRIDE) = pre1;
+      *reinterpret_cast<uint4*>(dst + 32 * GT_BSTRIDE) = pre2;
+      *reinterpret_cast<uint4*>(dst + 48 * GT_BSTRIDE) = pre3;
     }
     if (tid < DT_B)
       Bm[buf * DT_B + tid] = make_float2(__int_as_float(pn), __uint_as_float((uint64_t)bt + tid < be ? bt + (uint32_t)tid : SENTINEL));
@@ -1110,7 +1232,8 @@ __global__ void __launch_bounds__(256, 2) dense_gt_valu_kernel(DenseArgs A, cons
 #pragma unroll
         for (int r = 0; r < 4; r++) acc[t][r] = (acc_t)0;
     }
-    const uint8_t* Bp = Bt0 + buf * GT_BT_BYTES + (size_t)(lane & 15) * DT_BSTRIDE;
+    const uint8_t* Bp = Bt0 + buf * GT_BT_BYTES + (size_t)(lane & 15) * GT_BSTRIDE;
+    const uint32_t bsw = (uint32_t)(lane & 15) << 4;           // the row's swizzle (rows (lane & 15) + 16 t share it)
     const uint8_t* Ap = At + (size_t)(wave * DT_AW + q * 4) * astride + sg * DT_SEG;
     const uint32_t nc = nch > sg * 16u ? min(16u, nch - sg * 16u) : 0u;
     for (uint32_t j = 0; j < nc; j++) {
@@ -1118,7 +1241,7 @@ __global__ void __launch_bounds__(256, 2) dense_gt_valu_kernel(DenseArgs A, cons
 #pragma unroll
       for (int r = 0; r < 4; r++) av[r] = *reinterpret_cast<const uint4*>(Ap + (size_t)r * astride + j * 16);
 #pragma unroll
-      for (int t = 0; t < 4; t++) bv[t] = *reinterpret_cast<const uint4*>(Bp + (size_t)t * 16 * DT_BSTRIDE + j * 16);
+      for (int t = 0; t < 4; t++) bv[t] = *reinterpret_cast<const uint4*>(Bp + (size_t)t * 16 * GT_BSTRIDE + ((j * 16) ^ bsw));
       gt_chunk_accum<DT, METRIC>(acc, av, bv);
     }
     if (sg == nseg - 1) {
@@ -1140,6 +1263,8 @@ __global__ void __launch_bounds__(256, 2) dense_gt_valu_kernel(DenseArgs A, cons
         }
       }
       GT_COUNT(0, 1);
+      // (immediate inserts here: the contraction, not the selection, bounds these kernels -- u8 24.8 ms queued vs 25.2 -- and the
+      // queues would take the LDS of the second workgroup per CU)
       gt_select<NR>(S, dist, bid, skip, pplace, gtau_mine, A.nsplit, lane);
     }
     gt_lds_barrier();
@@ -1194,7 +1319,7 @@ bool dense_gt_eligible(const DeviceIndex& ix, uint32_t m, bool b_ids, bool segme
   return twobyte ? ix.pstride <= 256 : ix.pstride <= 512;        // matrix cores: one 256-byte segment; VALU register tile: two
 }
 static size_t dense_gt_lds(const DeviceIndex& ix) {
-  if (ix.dtype == PANN_F16 || ix.dtype == PANN_BF16) return GT_LDS_BYTES;
+  if (ix.dtype == PANN_F16 || ix.dtype == PANN_BF16) return GT_LDS_BYTES + GT_QUEUE_BYTES;      // matrix-core kernel: + the survivor queues
   const size_t nseg = (ix.pstride + DT_SEG - 1) / DT_SEG;
   return GT_LDS_BYTES + (size_t)DT_A * (nseg * DT_SEG + 16);
 }

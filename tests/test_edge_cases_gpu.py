@@ -215,6 +215,25 @@ def test_dropped_list_grows_instead_of_failing(oracle, beam):
     ix.close()
 
 
+def test_dropped_list_growth_is_bounded_by_running_the_batch_in_ranges(oracle):
+    """growing the dropped list for a whole large batch could ask for tens of GB (nq x min(limit, n) x 8 bytes).
+    Above a 1 GiB budget the batch runs in ranges of queries instead; the handle keeps a modest capacity afterwards.
+    100 000 queries x 1536 entries x 8 B = 1.2 GB -> two ranges."""
+    X, G = _line_graph(1500)
+    rng = np.random.default_rng(3)
+    Q = np.zeros((100_000, 8), np.float32); Q[:, 0] = rng.integers(0, 1500, len(Q)) + 0.25
+    Q[7, 0] = 1499.0                                             # at least one query that walks the whole line
+    o = oracle.batch_search(X, G, queries=Q, k=1, beam=16, cut=1.0, out_k=2)
+    assert o["visited_count"].max() > 600
+    ix = DeviceIndex(X, G)
+    g = ix.batch_search(Q, k=1, beam=16, cut=1.0, out_k=2)
+    _cmp(o, g)
+    assert g["status"][0] == 0 and 256 < ix.dropped_capacity <= 2048
+    g2 = ix.batch_search(Q[:1000], k=1, beam=16, cut=1.0, out_k=2)      # the next call starts from the kept capacity
+    _cmp(oracle.batch_search(X, G, queries=Q[:1000], k=1, beam=16, cut=1.0, out_k=2), g2)
+    ix.close()
+
+
 def test_dev_entry_reports_dropped_overflow_in_status_word(oracle):
     """pann_batch_search_dev performs no synchronisation: the status word is copied to pann_search_out::status on the
     launch stream; bit 2 = results invalid, reserve a larger list and launch again"""
