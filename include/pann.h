@@ -297,6 +297,13 @@ int pann_range_search(pann_index* idx, const void* queries, const uint32_t* quer
  * DESIGN.md "Build determinism".  times3 (optional): seconds spent in {tree, leaf kNN, MST}. */
 int pann_hcnng_build(pann_index* idx, uint32_t num_clusters, uint32_t cluster_size, uint32_t mst_deg,
                      uint64_t seed, double* times3);
+/* The stream the handle's calls run on (default: a private non-blocking stream).  A caller that produces the inputs of the
+ * _dev phases on its own stream (torch's current stream: the all-gathered rows of the multi-GPU build) passes that stream here
+ * once; work is then ordered by the stream and needs no synchronisation between the caller's kernels / collectives and the
+ * library's.  use_private != 0: back to the private stream (stream is ignored); otherwise `stream` is used as given -- NULL is
+ * the device's default stream, which is what torch's current stream usually is.  The stream must outlive its use by the handle. */
+int pann_index_set_stream(pann_index* idx, void* stream, int use_private);
+
 /* Per-handle tuning knobs; results never depend on them (0 = the library's own choice).  Unknown names: PANN_ERR_BAD_ARG.
  *   "forest_group": HCNNG -- the independent cluster trees (clusterEdge.h:146-153) are split level by level in groups of this
  *                   many trees (scratch: trees x n positions; default: as many as 2^31 positions allow)

@@ -65,7 +65,8 @@ using namespace pann;
 struct pann_index {
   DeviceIndex ix;
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // the stream every call of this handle runs on: own_stream, or the caller's (pann_index_set_stream)
+  hipStream_t own_stream = nullptr;
   Workspace ws, ws2, ws3, ws4;   // kernel scratch (search / prune / re-prune / rows of a batch)
   uint32_t vcap = 0;        // visited-list capacity used by the builder (grows on overflow)
   uint32_t dcap = 256;      // dropped-list capacity of the searches (pann_index_reserve_dropped; grows on overflow)
@@ -239,7 +240,8 @@ static int index_create_impl(pann_index** out, const void* points, uint64_t n, u
   ix.pstride = ix.lpc * ix.nch * 16;
   ix.max_deg = max_deg; ix.gstride = (max_deg + 15) / 16 * 16;
   auto fail = [&](int rc) { pann_index_destroy(idx); return rc; };
-  if (hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(PANN_ERR_HIP); }
+  if (hipStreamCreateWithFlags(&idx->own_stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(PANN_ERR_HIP); }
+  idx->stream = idx->own_stream;
   hipError_t e;
   if ((e = hipMalloc((void**)&ix.points, n * (size_t)ix.pstride)) != hipSuccess) return fail(hip_fail(e, "hipMalloc(points)"));
   if ((e = hipMalloc((void**)&ix.graph, n * (size_t)ix.gstride * 4)) != hipSuccess) return fail(hip_fail(e, "hipMalloc(graph)"));
@@ -275,7 +277,7 @@ void pann_index_destroy(pann_index* idx) {
   idx->ws.release(); idx->ws2.release(); idx->ws3.release(); idx->ws4.release();
   for (auto& s : idx->stage) s.release();
   idx->pin_in.release(); idx->pin_out.release();
-  if (idx->stream) (void)hipStreamDestroy(idx->stream);
+  if (idx->own_stream) (void)hipStreamDestroy(idx->own_stream);
   delete idx;
 }
 
@@ -322,6 +324,14 @@ int pann_index_clear_graph(pann_index* idx) {
   DeviceGuard g(idx->device);
   PANN_HIP(hipMemsetAsync(idx->ix.graph, 0xFF, (size_t)idx->ix.n * idx->ix.gstride * 4, idx->stream));
   PANN_HIP(hipStreamSynchronize(idx->stream));
+  return PANN_OK;
+}
+
+int pann_index_set_stream(pann_index* idx, void* stream, int use_private) {
+  if (int rc = check_idx(idx, "pann_index_set_stream")) return rc;
+  DeviceGuard g(idx->device);
+  PANN_HIP(hipStreamSynchronize(idx->stream));                    // nothing of this handle is left on the stream it leaves
+  idx->stream = use_private ? idx->own_stream : (hipStream_t)stream;
   return PANN_OK;
 }
 

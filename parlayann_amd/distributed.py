@@ -310,9 +310,12 @@ def vamana_build_sharded(n, R, L, alpha, num_passes, seed, phase_a, phase_b, fin
 
 def device_vamana_build_sharded(ix, R, L, alpha, num_passes=1, seed=1, sort_neighbors=True, min_split=None):
     """`vamana_build_sharded` on a DeviceIndex (replicated on every rank's GPU): the phases are the C-ABI's
-    pann_vamana_search_prune_dev / pann_vamana_apply_rows_dev on torch device tensors, the collective is RCCL's."""
+    pann_vamana_search_prune_dev / pann_vamana_apply_rows_dev on torch device tensors, the collective is RCCL's.  For the
+    duration of the build the handle runs on torch's current stream (pann_index_set_stream), so the phases, the all-gather
+    and torch's small kernels between them are ordered by ONE stream: no host synchronisation is added here."""
     dev = torch.device("cuda", ix._lib.pann_index_device(ix._h))
     stats = _new_build_stats()
+    ix.set_stream(torch.cuda.current_stream(dev).cuda_stream)
 
     def phase_a(ids, a):
         ids = ids.contiguous()
@@ -322,11 +325,13 @@ def device_vamana_build_sharded(ix, R, L, alpha, num_passes=1, seed=1, sort_neig
 
     def phase_b(ids, rows, a):
         ids = ids.contiguous(); rows = rows.contiguous()
-        torch.cuda.current_stream(dev).synchronize()      # the gathered rows were produced on torch's streams; the library runs on its own
         ix.vamana_apply_rows_dev(ids.data_ptr(), ids.numel(), rows.data_ptr(), R, a, stats=stats)
 
-    info = vamana_build_sharded(ix.n, R, L, alpha, num_passes, seed, phase_a, phase_b,
-                                finish=ix.vamana_sort_neighbors if sort_neighbors else None, device=dev, min_split=min_split)
+    try:
+        info = vamana_build_sharded(ix.n, R, L, alpha, num_passes, seed, phase_a, phase_b,
+                                    finish=ix.vamana_sort_neighbors if sort_neighbors else None, device=dev, min_split=min_split)
+    finally:
+        ix.set_stream(0, private=True)
     info["stats"] = stats
     return info
 
@@ -350,9 +355,12 @@ def device_hcnng_build_tree_parallel(ix, num_clusters, cluster_size, mst_deg, se
     stride = per * mst_deg
     slab = torch.empty((ix.n, stride), dtype=torch.int32, device=dev)
     times = np.zeros(3, np.float64)
-    check(ix._lib.pann_hcnng_build_trees_dev(ix._h, rank, world, mine, cluster_size, mst_deg, seed, C.c_void_p(slab.data_ptr()), stride,
-                                             times.ctypes.data_as(C.c_void_p)))
-    slabs = all_gather_tensor(slab)                                          # [W, n, stride]
-    torch.cuda.current_stream(dev).synchronize()          # the library's stream does not order itself behind torch's
-    check(ix._lib.pann_hcnng_assemble_dev(ix._h, C.c_void_p(slabs.data_ptr()), slabs.shape[0], stride, num_clusters, mst_deg))
+    ix.set_stream(torch.cuda.current_stream(dev).cuda_stream)     # trees, all-gather and assembly ordered by ONE stream
+    try:
+        check(ix._lib.pann_hcnng_build_trees_dev(ix._h, rank, world, mine, cluster_size, mst_deg, seed, C.c_void_p(slab.data_ptr()), stride,
+                                                 times.ctypes.data_as(C.c_void_p)))
+        slabs = all_gather_tensor(slab)                                      # [W, n, stride]
+        check(ix._lib.pann_hcnng_assemble_dev(ix._h, C.c_void_p(slabs.data_ptr()), slabs.shape[0], stride, num_clusters, mst_deg))
+    finally:
+        ix.set_stream(0, private=True)
     return {"tree_s": times[0], "leaf_knn_s": times[1], "mst_s": times[2], "bytes_gathered": int(slabs.numel()) * 4}

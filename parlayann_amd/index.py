@@ -176,6 +176,11 @@ class DeviceIndex:
         """empty graph again (Graph(maxDeg, n), graph.h:145-147), on the device"""
         check(self._lib.pann_index_clear_graph(self._h))
 
+    def set_stream(self, stream_ptr, private=False):
+        """pann_index_set_stream: run the handle's calls on the caller's stream (a hipStream_t as an integer; 0 = the device's
+        default stream, torch's usual current stream); private=True: back to the handle's own stream"""
+        check(self._lib.pann_index_set_stream(self._h, C.c_void_p(stream_ptr or None), 1 if private else 0))
+
     def set_option(self, name, value):
         """pann_index_set_option: per-handle tuning knobs ("forest_group", "gt_pieces"); results never depend on them"""
         check(self._lib.pann_index_set_option(self._h, name.encode(), int(value)))
