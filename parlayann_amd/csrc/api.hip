@@ -71,6 +71,8 @@ struct pann_index {
   uint32_t vcap = 0;        // visited-list capacity used by the builder (grows on overflow)
   uint32_t dcap = 256;      // dropped-list capacity of the searches (pann_index_reserve_dropped; grows on overflow)
   uint32_t gt_pieces = 0;   // pann_index_set_option("gt_pieces"): pieces of the base per query tile in pann_bruteforce_knn (0 = auto)
+  DevBuf code_rank, code_rows;   // filter-code table (filter_codes.hip): rank16[n], gcode[n][gstride]
+  int codes_state = 0;      // 0 not tried, 1 available (rank16 built), -1 unavailable (a slot class has 4 095 or more members) or switched off
   DevBuf stage[12];      // staging for host-pointer calls
   PinnedBuf pin_in, pin_out;   // packed pinned staging of pann_batch_search
 };
@@ -143,6 +145,7 @@ int check_idx(const pann_index* idx, const char* fn) {
 int upload_graph_rows(pann_index* idx, const uint32_t* h_rows, uint64_t m, const uint32_t* h_row_ids) {
   DeviceIndex& ix = idx->ix;
   if (m == 0) return PANN_OK;
+  ix.codes_valid = 0;                                   // rows change without their filter codes (filter_codes.hip)
   const size_t row_bytes = (size_t)(ix.max_deg + 1) * 4;
   // stream in slices so the staging buffer stays bounded (288 GB HBM, but host slabs can be huge)
   const uint64_t slice = std::max<uint64_t>(1, (256ull << 20) / row_bytes);
@@ -167,6 +170,29 @@ int upload_graph_rows(pann_index* idx, const uint32_t* h_rows, uint64_t m, const
   uint32_t bad = 0;
   PANN_HIP(hipMemcpy(&bad, idx->stage[9].p, 4, hipMemcpyDeviceToHost));
   if (bad) { set_error("graph upload: neighbour id out of range (>= number of points); those rows were left empty"); return PANN_ERR_BAD_ARG; }
+  return PANN_OK;
+}
+
+// The builder's L = 91..128 searches use the 12-bit filter-code table (filter_codes.hip) when every slot class is small
+// enough.  Called by the Vamana entry points before their searches: builds rank16 once per handle, and gcode from the
+// current graph whenever something outside the builder's row writers has changed the graph since.
+int ensure_filter_codes(pann_index* idx, uint32_t L) {
+  DeviceIndex& ix = idx->ix;
+  if (L <= 90 || L > 128 || idx->codes_state < 0) return PANN_OK;
+  if (ix.codes_valid) return PANN_OK;
+  if (idx->codes_state == 0) {
+    static const bool off = ab_env("PANN_NO_FILTER_CODES") != nullptr;      // diagnostic A/B switch
+    if (off) { idx->codes_state = -1; return PANN_OK; }
+    if (int rc = idx->code_rank.ensure((size_t)ix.n * 2 + 256)) return rc;
+    uint32_t max_rank = 0;
+    if (int rc = filter_codes_build_ranks(ix.n, FILTER_CODE_BITS, idx->ws2, idx->stream, idx->code_rank.as<uint16_t>(), &max_rank)) return rc;
+    if (max_rank >= 0xFFFu) { idx->codes_state = -1; idx->code_rank.release(); return PANN_OK; }      // a code would not fit 12 bits
+    if (int rc = idx->code_rows.ensure((size_t)ix.n * ix.gstride * 2 + 256)) return rc;
+    idx->codes_state = 1;
+    ix.rank16 = idx->code_rank.as<uint16_t>(); ix.gcode = idx->code_rows.as<uint16_t>();
+  }
+  if (int rc = filter_codes_rebuild_rows(ix, idx->stream)) return rc;
+  ix.codes_valid = 1;
   return PANN_OK;
 }
 
@@ -277,6 +303,7 @@ void pann_index_destroy(pann_index* idx) {
   idx->ws.release(); idx->ws2.release(); idx->ws3.release(); idx->ws4.release();
   for (auto& s : idx->stage) s.release();
   idx->pin_in.release(); idx->pin_out.release();
+  idx->code_rank.release(); idx->code_rows.release();
   if (idx->own_stream) (void)hipStreamDestroy(idx->own_stream);
   delete idx;
 }
@@ -323,6 +350,7 @@ int pann_index_clear_graph(pann_index* idx) {
   if (int rc = check_idx(idx, "pann_index_clear_graph")) return rc;
   DeviceGuard g(idx->device);
   PANN_HIP(hipMemsetAsync(idx->ix.graph, 0xFF, (size_t)idx->ix.n * idx->ix.gstride * 4, idx->stream));
+  if (idx->ix.gcode) PANN_HIP(hipMemsetAsync(idx->ix.gcode, 0xFF, (size_t)idx->ix.n * idx->ix.gstride * 2, idx->stream));   // codes of an empty graph
   PANN_HIP(hipStreamSynchronize(idx->stream));
   return PANN_OK;
 }
@@ -555,6 +583,7 @@ int pann_vamana_insert_batch(pann_index* idx, const uint32_t* batch_ids, uint64_
       set_error("ERROR: invalid point " + std::to_string(batch_ids[i]) + " given to batch_insert"); return PANN_ERR_BAD_ARG;
     }
   DeviceGuard g(idx->device);
+  if (int rc = ensure_filter_codes(idx, L)) return rc;
   if (int rc = idx->stage[2].ensure(m * 4)) return rc;
   PANN_HIP(hipMemcpyAsync(idx->stage[2].p, batch_ids, m * 4, hipMemcpyHostToDevice, idx->stream));
   if (idx->vcap < default_vcap(L)) idx->vcap = default_vcap(L);
@@ -572,6 +601,7 @@ int pann_vamana_search_prune_dev(pann_index* idx, const uint32_t* d_batch_ids, u
   if (L == 0 || L > 65536) { set_error("pann_vamana_search_prune_dev: L out of range"); return PANN_ERR_BAD_ARG; }
   if (start >= idx->ix.n || m > 0xFFFFFFF0ull) { set_error("pann_vamana_search_prune_dev: start / batch size out of range"); return PANN_ERR_BAD_ARG; }
   DeviceGuard g(idx->device);
+  if (int rc = ensure_filter_codes(idx, L)) return rc;
   if (idx->vcap < default_vcap(L)) idx->vcap = default_vcap(L);
   return vamana_search_prune_dev(idx->ix, idx->ws2, idx->ws, idx->stream, d_batch_ids, (uint32_t)m, start, R, L, alpha, &idx->vcap,
                                  d_rows_out, stats);
@@ -590,6 +620,7 @@ int pann_vamana_apply_rows_dev(pann_index* idx, const uint32_t* d_batch_ids, uin
 int pann_vamana_sort_neighbors(pann_index* idx) {
   if (int rc = check_idx(idx, "pann_vamana_sort_neighbors")) return rc;
   DeviceGuard g(idx->device);
+  idx->ix.codes_valid = 0;                              // the rows are permuted without their filter codes
   return sort_neighbors_dev(idx->ix, idx->stream);
 }
 
@@ -676,6 +707,8 @@ int pann_vamana_build_single_batch(pann_index* idx, uint32_t R, uint32_t L, doub
     PANN_HIP(hipGetLastError());
   }
   PANN_HIP(hipStreamSynchronize(idx->stream));
+  idx->ix.codes_valid = 0;                              // random_edges_kernel wrote rows
+  if (int rc = ensure_filter_codes(idx, L)) return rc;
   if (idx->vcap < default_vcap(L)) idx->vcap = default_vcap(L);
   for (int pass = 0; pass < num_passes; pass++) {
     const double a = (pass == num_passes - 1) ? alpha : 1.0;   // :173-178
@@ -683,7 +716,7 @@ int pann_vamana_build_single_batch(pann_index* idx, uint32_t R, uint32_t L, doub
                                   (uint32_t)n, 0u, R, L, a, &idx->vcap, stats))      // floor = 0, ceiling = m (:236-240)
       return rc;
   }
-  if (sort_neighbors) return sort_neighbors_dev(idx->ix, idx->stream);
+  if (sort_neighbors) { idx->ix.codes_valid = 0; return sort_neighbors_dev(idx->ix, idx->stream); }
   return PANN_OK;
 }
 
@@ -699,6 +732,7 @@ int pann_vamana_build(pann_index* idx, uint32_t R, uint32_t L, double alpha, int
   PANN_HIP(hipMemcpyAsync(idx->stage[2].p, perm.data(), n * 4, hipMemcpyHostToDevice, idx->stream));
   PANN_HIP(hipStreamSynchronize(idx->stream));
   const uint32_t* d_perm = idx->stage[2].as<uint32_t>();
+  if (int rc = ensure_filter_codes(idx, L)) return rc;
   if (idx->vcap < default_vcap(L)) idx->vcap = default_vcap(L);
   // vamana/index.h:206-209
   size_t max_batch = std::min<size_t>((size_t)(0.02 * (double)(float)n), 1000000ul);
@@ -724,7 +758,7 @@ int pann_vamana_build(pann_index* idx, uint32_t R, uint32_t L, double alpha, int
       inc++;
     }
   }
-  if (sort_neighbors) return sort_neighbors_dev(idx->ix, idx->stream);   // :180-185
+  if (sort_neighbors) { idx->ix.codes_valid = 0; return sort_neighbors_dev(idx->ix, idx->stream); }   // :180-185
   return PANN_OK;
 }
 
@@ -999,6 +1033,7 @@ int pann_hcnng_assemble_dev(pann_index* idx, const uint32_t* d_slabs, uint32_t n
   if (!d_slabs || mst_deg == 0) { set_error("pann_hcnng_assemble_dev: null / zero argument"); return PANN_ERR_BAD_ARG; }
   if ((uint64_t)ntrees * mst_deg > idx->ix.max_deg) { set_error("pann_hcnng_assemble_dev: max_deg < ntrees * mst_deg"); return PANN_ERR_BAD_ARG; }
   DeviceGuard g(idx->device);
+  idx->ix.codes_valid = 0;
   return hcnng_assemble_dev(idx->ix, idx->stream, d_slabs, nslabs, slab_stride, ntrees, mst_deg);
 }
 
@@ -1007,6 +1042,7 @@ int pann_hcnng_build(pann_index* idx, uint32_t num_clusters, uint32_t cluster_si
   if (int rc = check_idx(idx, "pann_hcnng_build")) return rc;
   if (num_clusters == 0 || mst_deg == 0) { set_error("pann_hcnng_build: num_clusters and mst_deg must be positive"); return PANN_ERR_BAD_ARG; }
   DeviceGuard g(idx->device);
+  idx->ix.codes_valid = 0;
   return hcnng_build_dev(idx->ix, idx->ws2, idx->stream, num_clusters, cluster_size, mst_deg, seed, times3);
 }
 

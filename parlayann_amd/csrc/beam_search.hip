@@ -93,6 +93,8 @@ struct BSParams {
   uint32_t prio_start;     // first block index that runs with raised issue priority (register-frontier beam-64 kernel)
   uint32_t hsplit;         // beam 65..128 in HBM mode: 0 whole table in HBM, 1 half, 2 three quarters of it in LDS
   uint32_t p24;            // ... whose LDS part holds planar 24-bit entries (n < 2^24 - 1)
+  const uint16_t* gcode;   // filter-code table (filter_codes.hip): codes of the neighbours, slot-aligned with the graph rows
+  const uint16_t* rank16;  // ... and of every id (start points)
   uint64_t* dropped; uint32_t dcap;  // [nq][dcap] visited entries that left a non-full frontier
   uint32_t* work_counter;  // persistent variant: next query to take
   uint32_t* status;        // [0] |= 1 on visited-list overflow, |= 2 on dropped-list overflow
@@ -236,6 +238,46 @@ __device__ __forceinline__ bool filter_update(uint32_t* H, uint32_t hmask, bool 
     }
     PANN_WSYNC();                                     // T (and the LDS part) may be touched by the next call
   }
+  return seen;
+}
+
+// The same replay on a table of 12-bit CLASS CODES (filter_codes.hip): slot s remembers the code of the id written last, and
+// "table[s] == a" is "table[s] == code(a)" because (slot, code) <-> id is a bijection.  4 096 slots take 6 KB of LDS: an 8-bit
+// plane P8[s] and a 4-bit plane, eight slots per dword of P4.  Two lanes of one instruction may own different nibbles of one
+// dword, so the nibble is written with ds_mskor_b32 (D = (D & ~mask) | data, atomic per lane).  Empty slot = 0xFFF (no code is).
+// Lanes that share a slot are found through the 1 KB byte scratch T as in the HBM-table form above.
+__device__ __forceinline__ bool filter_update_codes(uint8_t* P8, uint32_t* P4, uint32_t hmask, bool active, uint32_t a, uint32_t code,
+                                                    int lane, uint8_t* T) {
+  const uint32_t s = (uint32_t)hash64_2((uint64_t)a) & hmask;
+  const uint32_t sh = (s & 7u) * 4u;
+  uint32_t old = 0x1000u;
+  if (active) old = (uint32_t)P8[s] | (((P4[s >> 3] >> sh) & 0xFu) << 8);
+  const uint32_t t = s & 1023u;
+  if (active) T[t] = (uint8_t)lane;
+  PANN_WSYNC();
+  const uint32_t w = active ? (uint32_t)T[t] : (uint32_t)lane;
+  uint64_t losers = __ballot(active && w != (uint32_t)lane);
+  int prev = -1;       // last earlier lane with my slot
+  bool last = true;    // no later lane with my slot
+  while (losers) {
+    const int L = __ffsll((unsigned long long)losers) - 1;
+    const uint32_t sL = __builtin_amdgcn_readlane(s, L);
+    const uint64_t grp = __ballot(active && s == sL);
+    losers &= ~grp;
+    if (active && s == sL) {
+      const uint64_t below = grp & ((1ull << lane) - 1ull);
+      prev = below ? 63 - __clzll((unsigned long long)below) : -1;
+      last = (lane == 63) ? true : ((grp >> (lane + 1)) == 0ull);
+    }
+  }
+  const uint32_t a_prev = __shfl(a, prev < 0 ? lane : prev);
+  const bool seen = active && (prev >= 0 ? (a_prev == a) : (old == code));
+  if (active && last) {
+    P8[s] = (uint8_t)code;
+    const uint32_t addr = (uint32_t)(uintptr_t)(P4 + (s >> 3));          // LDS byte address (low 32 bits of the flat address)
+    asm volatile("ds_mskor_b32 %0, %1, %2" ::"v"(addr), "v"(0xFu << sh), "v"((code >> 8) << sh) : "memory");
+  }
+  PANN_WSYNC();                                          // T and the table may be touched by the next call
   return seen;
 }
 
@@ -775,8 +817,11 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES_B64) beam_search_b64_
 // per lane (entry e lives in lane e % 64, slot e / 64).  LDS per query: the 16 KB filter + a 128-entry
 // scatter scratch + candidates = 18.2 KB -> 9 queries per CU (the LDS-frontier kernel needs 19.9 KB).
 // =============================================================================================
-template <int DT, int METRIC, int LPC, bool NCH1, bool HASH_LDS>
+// CODES (with HASH_LDS): the whole filter in LDS as 12-bit class codes (filter_update_codes), the codes of a row's neighbours
+// read with the row from P.gcode -- the builder's searches when the index keeps the codes (filter_codes.hip).
+template <int DT, int METRIC, int LPC, bool NCH1, bool HASH_LDS, bool CODES = false>
 __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P) {
+  static_assert(!CODES || HASH_LDS, "the code table lives in LDS");
   constexpr int RB = 2;
   const int lane = threadIdx.x;
   extern __shared__ __align__(16) uint8_t smem[];
@@ -803,8 +848,14 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
   while (qi < P.nq) {
   uint32_t* H = HASH_LDS ? Hl : P.hash_global + ((size_t)blockIdx.x << P.bits);
   const uint32_t hb = HASH_LDS ? 0u : P.hsplit;
-  if (hb != 3) for (uint32_t i = lane; i < (hsize >> hb); i += PANN_WAVE) hstore<HASH_LDS>(H, i, SENTINEL);
-  if (hb) lds_part_clear(Lp, lane);
+  uint8_t* const P8 = reinterpret_cast<uint8_t*>(Hl);                    // CODES: 8-bit plane [hsize], then
+  uint32_t* const P4 = Hl + (hsize >> 2);                                 // ... the 4-bit plane, 8 slots per dword [hsize / 8]
+  if constexpr (CODES) {
+    for (uint32_t i = lane; i < (hsize >> 2) + (hsize >> 3); i += PANN_WAVE) Hl[i] = 0xFFFFFFFFu;
+  } else {
+    if (hb != 3) for (uint32_t i = lane; i < (hsize >> hb); i += PANN_WAVE) hstore<HASH_LDS>(H, i, SENTINEL);
+    if (hb) lds_part_clear(Lp, lane);
+  }
   const int64_t self = P.query_ids ? (int64_t)P.query_ids[qi] : -1;
   const uint8_t* qrow = P.query_ids ? P.points + (uint64_t)self * P.pstride : P.queries + (uint64_t)qi * P.qstride;
   QReg<DT> qreg{};
@@ -826,7 +877,8 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
   {   // start points (:66-70); nstarts <= 64 in this kernel
     const bool act = lane < (int)P.nstarts;
     const uint32_t a = act ? P.starts[(size_t)qi * P.starts_stride + lane] : 0u;
-    (void)filter_update<HASH_LDS>(H, hmask, act, a, lane, T, hb, Lp);
+    if constexpr (CODES) (void)filter_update_codes(P8, P4, hmask, act, a, act ? (uint32_t)P.rank16[a] : 0u, lane, T);
+    else (void)filter_update<HASH_LDS>(H, hmask, act, a, lane, T, hb, Lp);
     if (act) Pl[lane] = a;
     PANN_WSYNC();
     c = gather_distances<DT, METRIC, LPC, NCH1, 4, false>(P, qreg, qlds, Pl, P.nstarts, 0xFFFFFFFFu, C, c, lane);
@@ -835,7 +887,7 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
 
   // Speculative adjacency-row fetch: while the candidates of vertex v are gathered, the row of the frontier's NEXT
   // unvisited entry is already requested; it is the next vertex unless the merge puts something in front of it.
-  uint32_t pref_id = SENTINEL, pref_row = SENTINEL;
+  uint32_t pref_id = SENTINEL, pref_row = SENTINEL, pref_code = 0;
   bool first = true;
   for (;;) {
     bool do_merge = first;
@@ -855,7 +907,7 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
       // sequential loop) and ONE gather fetches the survivors of both -- twice the bytes in flight per wave in the phase
       // that is 52 % of this kernel's time.  If the candidates of row 1 alone end the skipping (or row 2 does not fit),
       // row 2 never happened: its candidates are cut off the list and its table writes are put back (FilterUndo).
-      if (PANN_B128_PAIR && P.skip_enabled && more_unvisited && P.gstride <= PANN_WAVE && nvis + 1 < P.limit) {
+      if (PANN_B128_PAIR && !CODES && P.skip_enabled && more_unvisited && P.gstride <= PANN_WAVE && nvis + 1 < P.limit) {
         uint64_t r0 = um0, r1 = um1;
         if (r0) r0 &= r0 - 1; else r1 &= r1 - 1;
         const int idx2 = r0 ? __ffsll((unsigned long long)r0) - 1 : 64 + __ffsll((unsigned long long)r1) - 1;
@@ -929,8 +981,9 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
       if (f == beam) cutoff_ord = (uint32_t)(entry_key(f - 1) >> 32);
 
       const uint32_t* row = P.graph + (size_t)cur * P.gstride;
+      const uint16_t* crow = CODES ? P.gcode + (size_t)cur * P.gstride : nullptr;
       const bool pref_hit = (pref_id == cur);
-      const uint32_t pref_val = pref_row;
+      const uint32_t pref_val = pref_row, pref_cval = pref_code;
       uint32_t next_id = SENTINEL;   // the entry after `cur` among the unvisited ones
       {
         uint64_t r0 = um0, r1 = um1;
@@ -943,15 +996,17 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
       pref_id = SENTINEL;
       for (uint32_t i0 = 0; i0 < P.gstride; i0 += PANN_WAVE) {
         const uint32_t i = i0 + lane;
-        uint32_t a = SENTINEL;
-        if (i0 == 0 && pref_hit) a = pref_val;
-        else if (i < P.gstride) a = row[i];
+        uint32_t a = SENTINEL, code = 0;
+        if (i0 == 0 && pref_hit) { a = pref_val; code = pref_cval; }
+        else if (i < P.gstride) { a = row[i]; if constexpr (CODES) code = crow[i]; }
         const bool act = (a != SENTINEL) && (i < P.degree_limit);
         const uint64_t am = __ballot(act);
         PANN_STAMP(1);
         if (am == 0ull) break;
         degsum += __popcll(am);
-        const bool seen = filter_update<HASH_LDS>(H, hmask, act, a, lane, T, hb, Lp);
+        bool seen;
+        if constexpr (CODES) seen = filter_update_codes(P8, P4, hmask, act, a, code, lane, T);
+        else seen = filter_update<HASH_LDS>(H, hmask, act, a, lane, T, hb, Lp);
         const bool keep = act && !seen && ((int64_t)a != self);
         const uint64_t km = __ballot(keep);
         const uint32_t m = __popcll(km);
@@ -964,6 +1019,7 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
         if (i0 == 0 && next_id != SENTINEL && P.query_ids) {
           pref_id = next_id;
           pref_row = (lane < (int)P.gstride) ? P.graph[(size_t)next_id * P.gstride + lane] : SENTINEL;
+          if constexpr (CODES) pref_code = (lane < (int)P.gstride) ? (uint32_t)P.gcode[(size_t)next_id * P.gstride + lane] : 0u;
         }
         if (m) c = gather_distances<DT, METRIC, LPC, NCH1, PANN_GU_B128(LPC, NCH1), false>(P, qreg, qlds, Pl, m, cutoff_ord, C, c, lane);
         PANN_WSYNC();
@@ -1122,6 +1178,7 @@ static uint32_t filter_bits(int64_t beam) {  // :52
 
 struct Plan {
   uint32_t bits, bcap, ccap, deg_eff, dcap, lds_bytes; bool hash_lds; uint32_t slots; bool b64; bool b128;
+  bool b128_codes; // beam 91..128 with the filter as 12-bit class codes in LDS (the index keeps the codes: filter_codes.hip)
   bool b128_hbm;   // beam 65..128 with the filter in HBM (persistent blocks)
   uint32_t hsplit; // ... of which the part with an LDS share (filter_update split mode)
   uint32_t p24;    // ... stored as planar 24-bit entries
@@ -1151,7 +1208,12 @@ static Plan make_plan(const DeviceIndex& ix, const SearchArgs& a) {
   }
   p.b128 = p.hash_lds && p.bcap == 128 && a.nstarts <= 64;
   p.b128_hbm = false;
-  if (p.b128) {
+  p.b128_codes = p.b128 && p.bits == FILTER_CODE_BITS && ix.codes_valid && ix.gcode && ix.rank16 && ix.gstride <= PANN_WAVE;
+  if (p.b128_codes) {        // 6 KB of table + the merge scratch (which doubles as the replay scratch T) + candidates + flags + query
+    p.ccap = (std::max<uint32_t>(beam / 8 + p.deg_eff, a.nstarts) + 7) / 8 * 8;
+    p.hsplit = 0; p.p24 = 0;
+    p.lds_bytes = (uint32_t)(128 * 8 + (size_t)p.ccap * 8 + 128 + (nch1 ? 0 : (size_t)ix.nch * ix.lpc * 16) + ((size_t)1 << p.bits) * 3 / 2);
+  } else if (p.b128) {
     p.ccap = (std::max<uint32_t>(beam / 8 + p.deg_eff, a.nstarts) + 7) / 8 * 8;
     // 16 KB of filter per query leaves 8 queries per CU (2 048 on the chip).  Larger batches put the table in HBM
     // (Infinity-Cache resident): one dependent load per adjacency row, 3x the queries per CU; measured +17 % on the
@@ -1189,6 +1251,9 @@ template <int DT, int METRIC, int LPC, bool NCH1>
 static hipError_t launch_variant(const BSParams& P, const Plan& p, hipStream_t stream) {
   if (p.b64) {   // frontier in registers
     auto kern = beam_search_b64_kernel<DT, METRIC, LPC, NCH1>;
+    hipLaunchKernelGGL(kern, dim3(P.nq), dim3(PANN_WAVE), p.lds_bytes, stream, P);
+  } else if (p.b128_codes) {   // two frontier entries per lane, filter of class codes
+    auto kern = beam_search_b128_kernel<DT, METRIC, LPC, NCH1, true, true>;
     hipLaunchKernelGGL(kern, dim3(P.nq), dim3(PANN_WAVE), p.lds_bytes, stream, P);
   } else if (p.b128) {   // two frontier entries per lane
     if (p.b128_hbm) {
@@ -1267,6 +1332,7 @@ int launch_beam_search(const DeviceIndex& ix, const SearchArgs& a, void* ws, siz
   }
   P.hsplit = p.b128_hbm ? p.hsplit : 0u;
   P.p24 = p.b128_hbm ? p.p24 : 0u;
+  P.gcode = ix.gcode; P.rank16 = ix.rank16;
   P.hash_global = p.hash_lds ? nullptr : (uint32_t*)(w + 256 + (size_t)a.nq * p.dcap * 8);
   P.out = a.out;
   P.stamps = nullptr;

@@ -40,6 +40,11 @@ struct DeviceIndex {
   uint32_t max_deg = 0;
   uint32_t gstride = 0;  // uint32 per graph row on the device
   uint32_t forest_group = 0;  // HCNNG: trees split level by level together (0 = as many as 2^31 positions allow)
+  // filter-code table of the beam-91..128 searches (filter_codes.hip): the code of every id and, slot-aligned with the graph rows,
+  // of every neighbour.  gcode is only read while codes_valid: every writer of graph rows either maintains it or clears the flag.
+  const uint16_t* rank16 = nullptr;   // [n]
+  uint16_t* gcode = nullptr;          // [n][gstride]
+  uint32_t codes_valid = 0;
 };
 
 // The kernels come in two families (PANN_LAYOUT_SWITCH): rows that are ONE 16-byte chunk per lane with 8 / 16 / 32
@@ -116,6 +121,11 @@ uint32_t dense_gt_slots(const DeviceIndex& ix, uint32_t m);
 bool leaf_knn_rows_eligible(const DeviceIndex& ix, uint32_t m);
 int leaf_knn_rows_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, const uint32_t* d_ids, const uint64_t* d_off,
                       const uint64_t* h_off, uint64_t nseg, uint32_t m, int exclude_same, uint32_t* d_out_ids, float* d_out_dists);
+
+// filter_codes.hip
+constexpr uint32_t FILTER_CODE_BITS = 12;      // the table size the codes are made for: beam 91..128 (beamSearch.h:52)
+int filter_codes_build_ranks(uint64_t n, uint32_t bits, Workspace& ws, hipStream_t st, uint16_t* rank16, uint32_t* max_rank_out);
+int filter_codes_rebuild_rows(const DeviceIndex& ix, hipStream_t st);
 
 // range_search.hip
 int range_search_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, const uint8_t* d_q, uint64_t q_stride,

@@ -107,6 +107,7 @@ struct GreedyArgs {
   uint32_t* rows_out; uint32_t rows_stride;  // [m x rows_stride] ids, SENTINEL padded (or null)
   uint32_t* cnt_out;                          // [m] (or null)
   uint32_t* graph; uint32_t gstride;          // direct write of the owner's row when rows_out == null
+  uint16_t* gcode; const uint16_t* rank16;    // ... with the filter codes of the new row (filter_codes.hip), or null
   uint32_t* dcmps;
   uint32_t m;
   uint32_t kcap;                              // lists up to this many keys are pruned in LDS
@@ -308,6 +309,10 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_PRUNE_MINWAVES) prune_greedy_k
   } else {
     uint32_t* row = A.graph + (size_t)p * A.gstride;
     for (uint32_t j = lane; j < A.gstride; j += PANN_WAVE) row[j] = j < nsel ? Out[j] : SENTINEL;
+    if (A.gcode) {
+      uint16_t* crow = A.gcode + (size_t)p * A.gstride;
+      for (uint32_t j = lane; j < A.gstride; j += PANN_WAVE) crow[j] = j < nsel ? A.rank16[Out[j]] : (uint16_t)0xFFFF;
+    }
   }
   if (lane == 0) A.dcmps[oi] += dc;
 }
@@ -354,12 +359,17 @@ __global__ void fixed_stride_setup_kernel(uint64_t* cand_base, uint32_t* seg_beg
   if (i < m) { cand_base[i] = (uint64_t)i * cand_stride; seg_begin[i] = i * seg_stride; }
 }
 
+// (gcode / rank16: the filter codes of the new rows are written with them, filter_codes.hip; null: not maintained)
 __global__ void scatter_rows_kernel(uint32_t* graph, uint32_t gstride, const uint32_t* owners,
-                                    const uint32_t* rows, uint32_t rows_stride, uint32_t m) {
+                                    const uint32_t* rows, uint32_t rows_stride, uint32_t m, uint16_t* gcode, const uint16_t* rank16) {
   const uint32_t oi = blockIdx.x;
   uint32_t* row = graph + (size_t)owners[oi] * gstride;
-  for (uint32_t j = threadIdx.x; j < gstride; j += blockDim.x)
-    row[j] = j < rows_stride ? rows[(size_t)oi * rows_stride + j] : SENTINEL;
+  uint16_t* crow = gcode ? gcode + (size_t)owners[oi] * gstride : nullptr;
+  for (uint32_t j = threadIdx.x; j < gstride; j += blockDim.x) {
+    const uint32_t a = j < rows_stride ? rows[(size_t)oi * rows_stride + j] : SENTINEL;
+    row[j] = a;
+    if (crow) crow[j] = a == SENTINEL ? (uint16_t)0xFFFF : rank16[a];
+  }
 }
 
 // reverse edges (:278-281): key = (target << 32) | position of the source in the batch
@@ -393,6 +403,7 @@ struct ReverseArgs {
   uint32_t* edge_src;           // [total] source vertex of each sorted edge
   uint32_t* heavy_owner; uint64_t* heavy_base; uint32_t* heavy_cnt; uint32_t* heavy_len;
   uint32_t* nheavy;
+  uint16_t* gcode; const uint16_t* rank16;   // filter codes kept in step with the rows (filter_codes.hip), or null
 };
 
 // per target vertex: append-without-repeats when the row stays within R (:292-294), else queue the
@@ -403,11 +414,13 @@ __global__ void __launch_bounds__(PANN_WAVE) reverse_light_kernel(ReverseArgs A)
   const uint32_t ng = *A.ngroups;
   if (g >= ng) return;
   __shared__ uint32_t Cn[1024];
+  __shared__ uint16_t Cc[1024];                 // the codes of Cn (only when A.gcode)
   const uint32_t lo = A.gstart[g];
   const uint32_t hi = (g + 1 < ng) ? A.gstart[g + 1] : *A.nvalid;
   const uint32_t c = hi - lo;
   const uint32_t v = (uint32_t)(A.ekeys[lo] >> 32);
   uint32_t* row = A.graph + (size_t)v * A.gstride;
+  uint16_t* crow = A.gcode ? A.gcode + (size_t)v * A.gstride : nullptr;
   uint32_t deg = 0;
   for (uint32_t i0 = 0; i0 < A.gstride; i0 += PANN_WAVE) {
     const uint32_t i = i0 + lane;
@@ -416,7 +429,7 @@ __global__ void __launch_bounds__(PANN_WAVE) reverse_light_kernel(ReverseArgs A)
   for (uint32_t j = lane; j < c; j += PANN_WAVE) {
     const uint32_t src = A.batch[(uint32_t)A.ekeys[lo + j]];
     A.edge_src[lo + j] = src;
-    if (c + deg <= A.R) Cn[j] = src;
+    if (c + deg <= A.R) { Cn[j] = src; if (crow) Cc[j] = A.rank16[src]; }
   }
   if (c + deg > A.R) {
     if (lane == 0) {
@@ -431,15 +444,17 @@ __global__ void __launch_bounds__(PANN_WAVE) reverse_light_kernel(ReverseArgs A)
   for (uint32_t i0 = 0; i0 < A.gstride; i0 += PANN_WAVE) {      // deg <= R <= gstride
     const uint32_t i = i0 + lane;
     const uint32_t a = (i < deg) ? row[i] : SENTINEL;
+    const uint16_t ac = (crow && i < deg) ? crow[i] : (uint16_t)0xFFFF;      // a kept neighbour keeps its code
     bool keep = (i < deg);
     if (keep) for (uint32_t j = 0; j < c; j++) keep &= (Cn[j] != a);
     const uint64_t km = __ballot(keep);
     __syncthreads();
-    if (keep) Cn[w + lanes_below(km, lane)] = a;
+    if (keep) { const uint32_t at = w + lanes_below(km, lane); Cn[at] = a; Cc[at] = ac; }
     w += __popcll(km);
   }
   __syncthreads();
   for (uint32_t j = lane; j < A.gstride; j += PANN_WAVE) row[j] = j < w ? Cn[j] : SENTINEL;
+  if (crow) for (uint32_t j = lane; j < A.gstride; j += PANN_WAVE) crow[j] = j < w ? Cc[j] : (uint16_t)0xFFFF;
 }
 
 // G[i].sort by distance to i (:180-185); ties by id
@@ -728,7 +743,8 @@ int vamana_apply_rows_dev(const DeviceIndex& ix, Workspace& ws, Workspace& ws2, 
   Bump b(ws.buf, ws.bytes); layout(b);
 
   // ---- :268-270 write the new out-neighbourhoods (only now: every search and prune of the batch saw the old graph)
-  hipLaunchKernelGGL(scatter_rows_kernel, dim3(m), dim3(PANN_WAVE), 0, st, ix.graph, ix.gstride, d_batch, d_rows, R, m);
+  uint16_t* const gcode = ix.codes_valid ? ix.gcode : nullptr;      // filter codes maintained with the rows (filter_codes.hip)
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(m), dim3(PANN_WAVE), 0, st, ix.graph, ix.gstride, d_batch, d_rows, R, m, gcode, ix.rank16);
   PANN_HIP(hipGetLastError());
 
   // ---- 3. reverse edges grouped by target (:278-282) ----
@@ -756,6 +772,7 @@ int vamana_apply_rows_dev(const DeviceIndex& ix, Workspace& ws, Workspace& ws2, 
     ra.graph = ix.graph; ra.gstride = ix.gstride; ra.R = R; ra.ekeys = ek_b; ra.gstart = d_gstart;
     ra.ngroups = d_scalars + 2; ra.nvalid = d_scalars + 1; ra.batch = d_batch; ra.edge_src = d_src;
     ra.heavy_owner = d_hown; ra.heavy_base = d_hbase; ra.heavy_cnt = d_hcnt; ra.heavy_len = d_hlen; ra.nheavy = d_scalars + 3;
+    ra.gcode = gcode; ra.rank16 = ix.rank16;
     hipLaunchKernelGGL(reverse_light_kernel, dim3(ngroups), dim3(PANN_WAVE), 0, st, ra);
     PANN_HIP(hipGetLastError());
     PANN_HIP(hipMemcpyAsync(&nheavy, d_scalars + 3, 4, hipMemcpyDeviceToHost, st));
@@ -789,6 +806,7 @@ int vamana_apply_rows_dev(const DeviceIndex& ix, Workspace& ws, Workspace& ws2, 
     GreedyArgs gb{};
     gb.pv = pb.pv; gb.dbytes = ix.dbytes; gb.owners = d_hown; gb.alpha = alpha; gb.R = R;
     gb.rows_out = nullptr; gb.rows_stride = 0; gb.cnt_out = nullptr; gb.graph = ix.graph; gb.gstride = ix.gstride;
+    gb.gcode = gcode; gb.rank16 = ix.rank16;
     gb.dcmps = h_ddc; gb.m = nheavy;
     if (int rc = run_prune(ix, pb, gb, hk_a, hk_b, (uint32_t)tk, h_tmp, stmp2, st, max_len)) return rc;
     if (stats) {
