@@ -38,7 +38,7 @@ namespace pann {
 /* beam 65..128: a whole adjacency row per memory round trip (16 groups in flight) was measured SLOWER than 4
    (C3 build search phase 1.50 s vs 1.19 s); rows of several chunks per lane halve the group count inside
    gather_tile, so they ask for 8 here (= 4 groups x 3 chunks in flight) */
-#define PANN_GU_B128(LPC, NCH1) ((NCH1) ? 4 : 8)
+#define PANN_GU_B128(LPC, NCH1) 4   /* round 3, with the filter-code table: 4 / 8 / 16 for multi-chunk rows = 0.720 / 0.743 / 0.885 s (C3 2M search phase) */
 #endif
 #ifndef PANN_MINWAVES
 #define PANN_MINWAVES 1
@@ -48,8 +48,13 @@ namespace pann {
    with it on) but OFF: measured on the C3-shaped 2M build, search phase 0.864 s without vs 0.91..0.93 s with it -- the kernel
    already moves 5.1 TB/s on the HBM side (81 % of the 6.3 TB/s random-row ceiling), so more bytes in flight buy nothing and the
    rows fetched for nothing when row 1 ends the skipping cost bandwidth.  It does pay when the table sits wholly in LDS and
-   occupancy is low (PANN_B128_SPLIT=3: 1.03 -> 0.98 s), which is slower than the default split anyway. */
+   occupancy is low (PANN_B128_SPLIT=3: 1.03 -> 0.98 s), which is slower than the default split anyway.
+   Round 3: with the filter-code table (CODES: the whole filter in 6 KB of LDS, no table traffic) it is ON for that variant:
+   C3 2M search phase 0.743 -> 0.712 s (PANN_B128_PAIR_CODES). */
 #define PANN_B128_PAIR 0
+#endif
+#ifndef PANN_B128_PAIR_CODES
+#define PANN_B128_PAIR_CODES 1
 #endif
 #ifndef PANN_B64_PREFETCH
 #define PANN_B64_PREFETCH 1   /* speculative adjacency-row fetch in the beam-64 kernel (0: A/B library builds) */
@@ -246,8 +251,18 @@ __device__ __forceinline__ bool filter_update(uint32_t* H, uint32_t hmask, bool 
 // plane P8[s] and a 4-bit plane, eight slots per dword of P4.  Two lanes of one instruction may own different nibbles of one
 // dword, so the nibble is written with ds_mskor_b32 (D = (D & ~mask) | data, atomic per lane).  Empty slot = 0xFFF (no code is).
 // Lanes that share a slot are found through the 1 KB byte scratch T as in the HBM-table form above.
+__device__ __forceinline__ void code_store(uint8_t* P8, uint32_t* P4, uint32_t s, uint32_t code) {
+  const uint32_t sh = (s & 7u) * 4u;
+  P8[s] = (uint8_t)code;
+  const uint32_t addr = (uint32_t)(uintptr_t)(P4 + (s >> 3));            // LDS byte address (low 32 bits of the flat address)
+  asm volatile("ds_mskor_b32 %0, %1, %2" ::"v"(addr), "v"(0xFu << sh), "v"((code >> 8) << sh) : "memory");
+}
+__device__ __forceinline__ void filter_undo_codes(uint8_t* P8, uint32_t* P4, const FilterUndo& u) {
+  if (u.wrote) code_store(P8, P4, u.s, u.old);
+  PANN_WSYNC();
+}
 __device__ __forceinline__ bool filter_update_codes(uint8_t* P8, uint32_t* P4, uint32_t hmask, bool active, uint32_t a, uint32_t code,
-                                                    int lane, uint8_t* T) {
+                                                    int lane, uint8_t* T, FilterUndo* undo = nullptr) {
   const uint32_t s = (uint32_t)hash64_2((uint64_t)a) & hmask;
   const uint32_t sh = (s & 7u) * 4u;
   uint32_t old = 0x1000u;
@@ -272,11 +287,8 @@ __device__ __forceinline__ bool filter_update_codes(uint8_t* P8, uint32_t* P4, u
   }
   const uint32_t a_prev = __shfl(a, prev < 0 ? lane : prev);
   const bool seen = active && (prev >= 0 ? (a_prev == a) : (old == code));
-  if (active && last) {
-    P8[s] = (uint8_t)code;
-    const uint32_t addr = (uint32_t)(uintptr_t)(P4 + (s >> 3));          // LDS byte address (low 32 bits of the flat address)
-    asm volatile("ds_mskor_b32 %0, %1, %2" ::"v"(addr), "v"(0xFu << sh), "v"((code >> 8) << sh) : "memory");
-  }
+  if (undo) { undo->s = s; undo->old = old; undo->wrote = active && last; }   // `old` of a slot group: the code on entry
+  if (active && last) code_store(P8, P4, s, code);
   PANN_WSYNC();                                          // T and the table may be touched by the next call
   return seen;
 }
@@ -907,7 +919,7 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
       // sequential loop) and ONE gather fetches the survivors of both -- twice the bytes in flight per wave in the phase
       // that is 52 % of this kernel's time.  If the candidates of row 1 alone end the skipping (or row 2 does not fit),
       // row 2 never happened: its candidates are cut off the list and its table writes are put back (FilterUndo).
-      if (PANN_B128_PAIR && !CODES && P.skip_enabled && more_unvisited && P.gstride <= PANN_WAVE && nvis + 1 < P.limit) {
+      if ((CODES ? PANN_B128_PAIR_CODES : PANN_B128_PAIR) && P.skip_enabled && more_unvisited && P.gstride <= PANN_WAVE && nvis + 1 < P.limit) {
         uint64_t r0 = um0, r1 = um1;
         if (r0) r0 &= r0 - 1; else r1 &= r1 - 1;
         const int idx2 = r0 ? __ffsll((unsigned long long)r0) - 1 : 64 + __ffsll((unsigned long long)r1) - 1;
@@ -917,17 +929,27 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
         const uint32_t cur2 = key_id(key2);
         uint32_t cutoff2 = BIG_ORD;
         if (f == beam) cutoff2 = (uint32_t)(entry_key(f - 1) >> 32);
-        uint32_t a1 = SENTINEL, a2 = SENTINEL;
+        uint32_t a1 = SENTINEL, a2 = SENTINEL, code1 = 0, code2 = 0;
         if (lane < (int)P.gstride) {
           a1 = (pref_id == cur) ? pref_row : P.graph[(size_t)cur * P.gstride + lane];
           a2 = P.graph[(size_t)cur2 * P.gstride + lane];
+          if constexpr (CODES) {
+            code1 = (pref_id == cur) ? pref_code : (uint32_t)P.gcode[(size_t)cur * P.gstride + lane];
+            code2 = P.gcode[(size_t)cur2 * P.gstride + lane];
+          }
         }
         pref_id = SENTINEL;
         const bool act1 = (a1 != SENTINEL) && ((uint32_t)lane < P.degree_limit);
         const bool act2 = (a2 != SENTINEL) && ((uint32_t)lane < P.degree_limit);
-        const bool seen1 = filter_update<HASH_LDS>(H, hmask, act1, a1, lane, T, hb, Lp);
         FilterUndo u2;
-        const bool seen2 = filter_update<HASH_LDS>(H, hmask, act2, a2, lane, T, hb, Lp, &u2);
+        bool seen1, seen2;
+        if constexpr (CODES) {
+          seen1 = filter_update_codes(P8, P4, hmask, act1, a1, code1, lane, T);
+          seen2 = filter_update_codes(P8, P4, hmask, act2, a2, code2, lane, T, &u2);
+        } else {
+          seen1 = filter_update<HASH_LDS>(H, hmask, act1, a1, lane, T, hb, Lp);
+          seen2 = filter_update<HASH_LDS>(H, hmask, act2, a2, lane, T, hb, Lp, &u2);
+        }
         const bool keep1 = act1 && !seen1 && ((int64_t)a1 != self);
         const bool keep2 = act2 && !seen2 && ((int64_t)a2 != self);
         const uint64_t km1 = __ballot(keep1), km2 = __ballot(keep2);
@@ -946,7 +968,11 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
         PANN_WSYNC();
         // the reference's decision after vertex 1 (another unvisited entry exists): skip iff its list is still short
         const bool two = both && (c_after1 == 0 || c_after1 < beam / 8);
-        if (!two) { c = c_after1; filter_undo<HASH_LDS>(H, u2, hb, Lp); }
+        if (!two) {
+          c = c_after1;
+          if constexpr (CODES) filter_undo_codes(P8, P4, u2);
+          else filter_undo<HASH_LDS>(H, u2, hb, Lp);
+        }
         // commit: visited.insert(current) (:112-114), counters
         if (cur_idx < 64) { if (lane == cur_idx) fflag[0] = 1; } else { if (lane == cur_idx - 64) fflag[1] = 1; }
         if (two) { if (idx2 < 64) { if (lane == idx2) fflag[0] = 1; } else { if (lane == idx2 - 64) fflag[1] = 1; } }
