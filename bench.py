@@ -19,6 +19,8 @@ Modes (a "step" is one pass of the mode's hot path, inputs
           (vamana/index.h:188-316 is what the ranks run between the collectives); one step = one whole build.  Strong scaling.
   c5build HCNNG build (T2I-shaped --n x 200 int8 MIPS, default 10M, 30 trees) with the trees split over the ranks; one
           step = one whole build.  Strong scaling.
+  hbm_leg the second leg of the default run by itself (12.5M x 128 fp16 table, same kernel / beam / k): what the rocprofv3 passes
+          of profiles/r03_bench12m_* run, so that its launches are not mixed with the 1M-table launches of the same grid size.
   launchcheck  no GPU work at all: the launcher, the process group (gloo when no GPU is visible) and the timing contract
           with an empty step; prints n_gpus / ranks_seen.  What tests/test_bench_launcher_cpu.py runs.
 """
@@ -33,7 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
-MODES = ("query", "c4", "c3build", "c5build", "launchcheck")
+MODES = ("query", "c4", "c3build", "c5build", "hbm_leg", "launchcheck")
 
 
 def log(*a):
@@ -74,7 +76,8 @@ def parse_args(argv=None):
     if args.warmup is None:
         args.warmup = 1 if build else 3
     if args.n is None:
-        args.n = {"query": 1_000_000, "c4": 12_500_000, "c3build": 10_000_000, "c5build": 10_000_000, "launchcheck": 0}[args.mode]
+        args.n = {"query": 1_000_000, "c4": 12_500_000, "c3build": 10_000_000, "c5build": 10_000_000, "hbm_leg": 12_500_000,
+                  "launchcheck": 0}[args.mode]
     return args
 
 
@@ -102,7 +105,11 @@ def launch_ranks(n_ranks, argv):
 
     def relay():
         for raw in procs[0].stdout:
-            lines.append(raw.decode("utf-8", "replace"))
+            line = raw.decode("utf-8", "replace")
+            if line.lstrip().startswith("{"):
+                lines.append(line)                      # rank 0's JSON line(s): the launcher's own stdout
+            else:
+                sys.stderr.write(line)                  # anything else a library printed on stdout (gloo's connection notes)
     t = threading.Thread(target=relay, daemon=True)
     t.start()
     rc = 0
@@ -258,7 +265,7 @@ def search_leg(rk, ix, Q, args, beam, steps, warmup):
             "ids": d_ids}
 
 
-def committed_traffic(args):
+def committed_traffic(args, key=None):
     """HBM-side bytes of ONE launch are not measurable from inside this process (rocprofv3 counters need their own passes):
     taken from the committed profile of the SAME workload when there is one, and labelled as such"""
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -266,7 +273,8 @@ def committed_traffic(args):
         return None, None
     try:
         tj = json.load(open(tpath))
-        key = {"n": args.n, "nq": args.nq, "beam": args.beam, "dtype": args.dtype, "d": args.d, "R": args.R, "data": args.data}
+        if key is None:
+            key = {"n": args.n, "nq": args.nq, "beam": args.beam, "dtype": args.dtype, "d": args.d, "R": args.R, "data": args.data}
         for ent in (tj if isinstance(tj, list) else [tj]):
             if all(ent.get(k) == v for k, v in key.items()):
                 return ent.get("hbm_bytes_per_launch"), ent.get("source", "profiles/traffic_latest.json")
@@ -302,7 +310,12 @@ def hbm_resident_leg(rk, args):
     gt_ids, gt_d = ix.bruteforce_knn(Q, 100)
     rec = recall_at_k(r["ids"].cpu().numpy().view(np.uint32), gt_ids, gt_d, args.k)
     ix.close()
-    return {"workload": f"{args.hbm_n}x128 integer-valued f16 (sift_like geometry, noise {noise}, generated on the device), "
+    traffic, traffic_src = (None, None)
+    if args.hbm_noise is None:
+        traffic, traffic_src = committed_traffic(args, {"n": args.hbm_n, "nq": args.nq, "beam": 64, "dtype": "f16", "d": 128, "R": 64, "data": "hbm_leg"})
+    return {"traffic": traffic, "traffic_source": traffic_src,
+            "traffic_frac": (traffic / (r["kernel_ms"] / 1e3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+            "workload": f"{args.hbm_n}x128 integer-valued f16 (sift_like geometry, noise {noise}, generated on the device), "
                         f"Vamana R=64 L=128 alpha=1.15 x2 built on the device, {args.nq} queries/step, beam=64 k={args.k}",
             "table_bytes": int(args.hbm_n) * 256, "queries_per_s": args.nq / (r["ms_per_step"] / 1e3), "ms_per_step": r["ms_per_step"],
             "kernel": kernel_name(64), "kernel_ms": r["kernel_ms"], "algorithmic_bytes_per_launch": r["alg_bytes"],
@@ -534,6 +547,23 @@ def mode_c5build(rk, args):
     ix.close()
 
 
+def mode_hbm_leg(rk, args):
+    args.hbm_n = args.n
+    leg = hbm_resident_leg(rk, args)
+    if rk.rank == 0:
+        print(json.dumps({
+            "metric": "QPS @ recall@10>=0.95 on the HBM-resident table (second leg of the default run, by itself)",
+            "value": leg["queries_per_s"], "unit": "queries/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": leg["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+            "data": "synthetic", "config": {"workload": leg["workload"], "n": args.n, "d": 128, "nq_per_gpu": args.nq, "beam": 64, "k": args.k},
+            "recall_at_10": leg["recall_at_10"], "recall_ok": leg["recall_ok"], "avg_visited": leg["avg_visited"],
+            "avg_dist_cmps": leg["avg_dist_cmps"], "build_s": leg["build_s"],
+            "roofline": {"bound": "hbm", "achieved": leg["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": leg["frac"],
+                         "traffic": None, "kernel": leg["kernel"], "kernel_ms": leg["kernel_ms"],
+                         "algorithmic_bytes_per_launch": leg["algorithmic_bytes_per_launch"]}}), flush=True)
+    return 0 if leg["recall_ok"] else 3
+
+
 def mode_launchcheck(rk, args):
     elapsed = rk.timed(lambda: None, args.steps, args.warmup)
     if rk.rank == 0:
@@ -585,7 +615,7 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))          # nothing above has imported torch or touched the GPU
     rk = Rank(args)
-    rc = {"query": mode_query, "c4": mode_c4, "c3build": mode_c3build, "c5build": mode_c5build,
+    rc = {"query": mode_query, "c4": mode_c4, "c3build": mode_c3build, "c5build": mode_c5build, "hbm_leg": mode_hbm_leg,
           "launchcheck": mode_launchcheck}[args.mode](rk, args)
     rk.finish()
     sys.exit(rc or 0)

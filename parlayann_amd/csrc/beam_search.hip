@@ -59,6 +59,12 @@ namespace pann {
 #ifndef PANN_B64_PREFETCH
 #define PANN_B64_PREFETCH 1   /* speculative adjacency-row fetch in the beam-64 kernel (0: A/B library builds) */
 #endif
+#ifndef PANN_B64_PAIR
+/* beam <= 64: two vertices per memory round trip while merges are skipped (the b128 form above, on the register frontier of
+   the beam-64 kernel): one query's chain of dependent round trips gets a third shorter, which is what the tail of a 10K-query
+   launch consists of.  A/B in profiles/r03_b64_pair.txt. */
+#define PANN_B64_PAIR 0
+#endif
 #ifndef PANN_MINWAVES_B64
 #define PANN_MINWAVES_B64 7   /* at least 7 waves per SIMD (<= 72 VGPRs); the kernel uses 61 -> 8 waves, LDS caps a CU at 30 queries */
 #endif
@@ -695,8 +701,11 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES_B64) beam_search_b64_
       const bool pref_hit = PANN_B64_PREFETCH && (pref_id == cur);
       const uint32_t pref_val = pref_row;
       pref_id = SENTINEL;
+      const uint64_t rest1 = um & (um - 1);
+      // two vertices this iteration? (nvis already counts `cur`: a second visit needs nvis < limit)
+      const bool pair_try = PANN_B64_PAIR && P.skip_enabled && rest1 != 0ull && P.gstride <= PANN_WAVE && nvis < P.limit;
       if (PANN_B64_PREFETCH) {
-        const uint64_t rest = um & (um - 1);
+        const uint64_t rest = pair_try ? (rest1 & (rest1 - 1)) : rest1;      // the entry after the one(s) visited now
         if (rest) {
           pref_id = key_id(readlane64(fkey, __ffsll((unsigned long long)rest) - 1));
           const uint32_t* np = P.graph + (size_t)pref_id * P.gstride + min((uint32_t)lane, P.gstride - 1);
@@ -705,6 +714,65 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES_B64) beam_search_b64_
       }
 
       const uint32_t* row = P.graph + (size_t)cur * P.gstride;
+      if (pair_try) {
+        // While merges are skipped (:162-168) the frontier and the cutoff do not change, so the vertex after `cur` is known:
+        // the second unvisited entry.  Both adjacency rows are fetched together, the filter is replayed row after row and ONE
+        // gather fetches the survivors of both.  If the candidates of row 1 alone end the skipping (or row 2 does not fit the
+        // candidate list), row 2 never happened: its candidates are cut off and its table writes are put back.
+        const int idx2 = __ffsll((unsigned long long)rest1) - 1;
+        const bool more_after2 = (rest1 & (rest1 - 1)) != 0ull;
+        const uint64_t key2 = readlane64(fkey, idx2);
+        const uint32_t cur2 = key_id(key2);
+        uint32_t a1 = SENTINEL, a2 = SENTINEL;
+        if (lane < (int)P.gstride) {
+          a1 = pref_hit ? pref_val : row[lane];
+          a2 = P.graph[(size_t)cur2 * P.gstride + lane];
+        }
+        const bool act1 = (a1 != SENTINEL) && ((uint32_t)lane < P.degree_limit);
+        const bool act2 = (a2 != SENTINEL) && ((uint32_t)lane < P.degree_limit);
+        PANN_STAMP(1);
+        const bool seen1 = filter_update<true>(H, hmask, act1, a1, lane);
+        FilterUndo u2;
+        const bool seen2 = filter_update<true>(H, hmask, act2, a2, lane, nullptr, 0, LdsPart{nullptr, 0, 0}, &u2);
+        const bool keep1 = act1 && !seen1 && ((int64_t)a1 != self);
+        const bool keep2 = act2 && !seen2 && ((int64_t)a2 != self);
+        const uint64_t km1 = __ballot(keep1), km2 = __ballot(keep2);
+        const uint32_t m1 = __popcll(km1), m2 = __popcll(km2);
+        const bool both = (c + m1 + m2 <= P.ccap);                   // the candidate list is sized for beam/8 - 1 + ONE row
+        if (keep1) Pl[lanes_below(km1, lane)] = a1;
+        if (both && keep2) Pl[m1 + lanes_below(km2, lane)] = a2;
+        PANN_WSYNC();
+        PANN_STAMP(2);
+        uint32_t c_after1 = c;
+        if (both) {
+          if (m1 + m2) c = gather_distances_split<DT, METRIC, LPC, NCH1, PANN_GU>(P, qreg, qlds, Pl, m1 + m2, m1, cutoff_ord, C, c, lane, &c_after1);
+        } else {
+          if (m1) c = gather_distances<DT, METRIC, LPC, NCH1, PANN_GU>(P, qreg, qlds, Pl, m1, cutoff_ord, C, c, lane);
+          c_after1 = c;
+        }
+        PANN_WSYNC();
+        PANN_STAMP(3);
+        // the reference's decision after vertex 1 (another unvisited entry exists): skip iff its list is still short
+        const bool two = both && (c_after1 == 0 || c_after1 < beam / 8);
+        if (!two) { c = c_after1; filter_undo<true>(H, u2, 0, LdsPart{nullptr, 0, 0}); }
+        if (two) {
+          if (lane == idx2) fflag = 1;
+          if (lane == 0 && P.out.visited_cap) {
+            if (nvis < P.out.visited_cap) {
+              if (P.out.visited_ids) P.out.visited_ids[(size_t)qi * P.out.visited_cap + nvis] = cur2;
+              if (P.out.visited_dists) P.out.visited_dists[(size_t)qi * P.out.visited_cap + nvis] = key_dist(key2);
+            } else {
+              atomicOr(P.status, 1u);
+            }
+          }
+          nvis++;
+        }
+        degsum += __popcll(__ballot(act1)) + (two ? __popcll(__ballot(act2)) : 0u);
+        dcmps += m1 + (two ? m2 : 0u);
+        const bool more_left = two ? more_after2 : true;
+        const bool skip = (c == 0) || (c < beam / 8 && more_left);
+        do_merge = !skip;
+      } else {
       for (uint32_t i0 = 0; i0 < P.gstride; i0 += PANN_WAVE) {
         const uint32_t i = i0 + lane;
         uint32_t a = SENTINEL;
@@ -729,6 +797,7 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES_B64) beam_search_b64_
       }
       const bool skip = (c == 0) || (P.skip_enabled && c < beam / 8 && more_unvisited);   // :162-168
       do_merge = !skip;
+      }   // single-vertex path
     }
     if (do_merge) {
       const uint32_t f_old = f;

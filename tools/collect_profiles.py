@@ -13,9 +13,10 @@ ap.add_argument("tag")
 ap.add_argument("--n", type=int, default=1_000_000); ap.add_argument("--nq", type=int, default=10_000)
 ap.add_argument("--dtype", default="f16"); ap.add_argument("--d", type=int, default=128); ap.add_argument("--R", type=int, default=64)
 ap.add_argument("--beam", type=int, default=64); ap.add_argument("--data", default="sift1m_like"); ap.add_argument("--note", default="")
+ap.add_argument("--bench-args", default=None, help="the bench.py arguments of the profiled runs, for the header lines (default: derived from the key)")
 a = ap.parse_args()
 tag, grid = a.tag, f"grid={a.nq * 64}"
-bargs = f"--n {a.n} --nq {a.nq} --dtype {a.dtype} --d {a.d} --R {a.R} --beam {a.beam} --data {a.data}"
+bargs = a.bench_args or f"--n {a.n} --nq {a.nq} --dtype {a.dtype} --d {a.d} --R {a.R} --beam {a.beam} --data {a.data}"
 s = open(f"gpurun_out/{tag}_summary_stats.txt").read().splitlines()
 out = [f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline {bargs} --steps 20   (MI355X, {tag}) {a.note}",
        "# whole process: includes the Vamana build of the index (its searches run beam_search_b128_kernel, L=128) and the brute-force ground truth"]
