@@ -90,3 +90,12 @@ def test_reference_signature_tu_compiles_without_a_gpu():
                            os.path.join(ROOT, "tests", "host_api_check.cpp"), "-L" + os.path.join(ROOT, "parlayann_amd", "lib"),
                            "-lpann", "-Wl,-rpath," + os.path.join(ROOT, "parlayann_amd", "lib")])
     assert os.path.exists(exe)
+
+
+def test_kernels_with_hand_issued_loads_do_not_spill():
+    """a register that receives a hand-issued load (beam-64 row prefetch, leaf-kNN LDS pipeline) must never be spilled
+    or copied before its hand-written wait; the built code objects are checked for scratch / VGPR spills / the 72-VGPR bound"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_kernel_regs.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
