@@ -308,8 +308,13 @@ int pann_index_set_stream(pann_index* idx, void* stream, int use_private);
  *   "forest_group": HCNNG -- the independent cluster trees (clusterEdge.h:146-153) are split level by level in groups of this
  *                   many trees (scratch: trees x n positions; default: as many as 2^31 positions allow)
  *   "gt_pieces"   : pann_bruteforce_knn -- the base is cut into this many pieces per 64-query tile (default: the count that
- *                   fills whole rounds of the 256 CUs best) */
+ *                   fills whole rounds of the 256 CUs best)
+ *   "filter_codes": 1 (default) / 0 -- the Vamana builder's L = 91..128 searches keep the lossy filter (beamSearch.h:52-59) as
+ *                   12-bit class codes in LDS when every slot class has fewer than 4 095 members (n below ~16M), else as ids */
 int pann_index_set_option(pann_index* idx, const char* name, int64_t value);
+/* the current value; for "filter_codes": 1 while the class codes are in step with the graph (the next beam-91..128 search uses
+ * them), 0 otherwise; -1: unknown name */
+int64_t pann_index_get_option(const pann_index* idx, const char* name);
 
 /* Sharded index: nlists result lists per query -- the output of ONE all-gather of every shard's
  * top-k -- laid out [nlists][nq][row_stride]: row (w, q) holds k_in ids at d_ids and k_in distances at d_dists (0xFFFFFFFF =

@@ -77,6 +77,7 @@ SIGNATURES = {
     "pann_index_clear_graph": (C.c_int, [C.c_void_p]),
     "pann_index_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "pann_index_set_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "pann_index_get_option": (C.c_int64, [C.c_void_p, C.c_char_p]),
     "pann_batch_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
                                     C.c_uint32, C.POINTER(QueryParams), C.POINTER(SearchOut)]),
     "pann_batch_search_per_query_starts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,

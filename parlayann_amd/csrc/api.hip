@@ -355,6 +355,15 @@ int pann_index_clear_graph(pann_index* idx) {
   return PANN_OK;
 }
 
+int64_t pann_index_get_option(const pann_index* idx, const char* name) {
+  if (!idx || !name) return -1;
+  const std::string nm = name;
+  if (nm == "forest_group") return idx->ix.forest_group;
+  if (nm == "gt_pieces") return idx->gt_pieces;
+  if (nm == "filter_codes") return idx->ix.codes_valid ? 1 : 0;         // are the class codes in step with the graph right now?
+  return -1;
+}
+
 int pann_index_set_stream(pann_index* idx, void* stream, int use_private) {
   if (int rc = check_idx(idx, "pann_index_set_stream")) return rc;
   DeviceGuard g(idx->device);
@@ -369,6 +378,10 @@ int pann_index_set_option(pann_index* idx, const char* name, int64_t value) {
   if (value < 0 || value > 0x7FFFFFFF) { set_error("pann_index_set_option: value out of range"); return PANN_ERR_BAD_ARG; }
   if (nm == "forest_group") idx->ix.forest_group = (uint32_t)value;
   else if (nm == "gt_pieces") idx->gt_pieces = (uint32_t)value;
+  else if (nm == "filter_codes") {          // 0: the beam-91..128 searches use the id table even where the class codes are available
+    idx->ix.codes_valid = 0;
+    idx->codes_state = value ? (idx->ix.rank16 ? 1 : 0) : -2;
+  }
   else { set_error("pann_index_set_option: unknown option '" + nm + "'"); return PANN_ERR_BAD_ARG; }
   return PANN_OK;
 }

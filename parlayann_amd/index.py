@@ -181,6 +181,9 @@ class DeviceIndex:
         default stream, torch's usual current stream); private=True: back to the handle's own stream"""
         check(self._lib.pann_index_set_stream(self._h, C.c_void_p(stream_ptr or None), 1 if private else 0))
 
+    def get_option(self, name):
+        return int(self._lib.pann_index_get_option(self._h, name.encode()))
+
     def set_option(self, name, value):
         """pann_index_set_option: per-handle tuning knobs ("forest_group", "gt_pieces"); results never depend on them"""
         check(self._lib.pann_index_set_option(self._h, name.encode(), int(value)))

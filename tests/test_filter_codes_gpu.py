@@ -72,3 +72,35 @@ def test_sorted_build_and_clear_graph_keep_working(oracle):
         np.testing.assert_array_equal(o["ids"], g["ids"]); np.testing.assert_array_equal(o["dist_cmps"], g["dist_cmps"])
         ix.clear_graph()
     ix.close()
+
+
+def test_codes_can_be_switched_off_and_graphs_do_not_depend_on_them(oracle):
+    n, R, L = 20000, 32, 128
+    X = datasets.sift_like(n, 64, seed=21, dtype=np.uint8)
+    a = DeviceIndex(X, max_degree=R); b = DeviceIndex(X, max_degree=R)
+    b.set_option("filter_codes", 0)
+    sa = a.vamana_build(R, L, 1.2, num_passes=2, seed=4, sort_neighbors=False)
+    sb = b.vamana_build(R, L, 1.2, num_passes=2, seed=4, sort_neighbors=False)
+    assert a.get_option("filter_codes") == 1 and b.get_option("filter_codes") == 0
+    np.testing.assert_array_equal(a.get_graph(), b.get_graph())
+    assert sa.search_dist_cmps == sb.search_dist_cmps and sa.visited_total == sb.visited_total
+    a.vamana_sort_neighbors()
+    assert a.get_option("filter_codes") == 0                      # the sort permuted the rows: codes stale until the next build call
+    a.close(); b.close()
+
+
+def test_tables_too_large_for_12_bit_codes_fall_back_to_ids():
+    """17.2M points: 4 199 ids per slot class on average, more than a 12-bit code can number -- the builder must notice when it
+    builds the codes and keep the id table (a short insert on the big table: no oracle at this size, the assertions are that the
+    fallback engaged and that the batch was inserted)"""
+    n = 17_200_000
+    rng = np.random.default_rng(5)
+    X = rng.integers(0, 256, (n, 8), dtype=np.uint8)
+    ix = DeviceIndex(X, max_degree=16)
+    batch = rng.choice(n, 20000, replace=False).astype(np.uint32)
+    st = ix.vamana_insert_batch(batch[:1], 16, 128, 1.2, start=int(batch[0]))
+    st = ix.vamana_insert_batch(batch, 16, 128, 1.2, start=int(batch[0]))
+    assert ix.get_option("filter_codes") == 0 and st.visited_total > 0
+    r = ix.batch_search(queries=X[batch[:100]], k=5, beam=128, starts=(int(batch[0]),))
+    assert np.isin(r["ids"][:, 0], batch).all()                  # what a search reaches are inserted points (a one-batch star graph)
+    ix.close()
