@@ -809,16 +809,24 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES_B64) beam_search_b64_
         const bool fl = lane < (int)f;
         uint32_t myp = 0, rank_c = 0, below_f = 0;
         uint64_t live_mask = 0;
+        // 64-bit compares issue at 2.5 x the cost of 32-bit ones on gfx950 (tools/valu_rate.hip), so the loop makes two of them
+        // per candidate instead of five: equal keys <=> equal ids (a vertex's distance to this query is one deterministic
+        // value, whichever row offered it), and "frontier entry below the candidate" is the complement of "candidate below the
+        // entry" once no entry is equal (free lanes hold KEY_INF: above every candidate, masked out by vmask).
+        const uint64_t vmask = __ballot(fl);
+        const uint32_t cid = (uint32_t)ckey, fid = (uint32_t)fkey;
         for (uint32_t i = 0; i < cc; i++) {
           const uint64_t kk = readlane64(ckey, (int)i);
-          const uint64_t ltm = __ballot(fl && fkey < kk);
-          const uint64_t eqm = __ballot(fl && fkey == kk);               // already in the frontier (set_union)
-          const uint64_t dupm = __ballot(lane < (int)i && ckey == kk);   // duplicate (std::unique)
+          const uint32_t kid = (uint32_t)kk;
+          const bool g = kk < fkey;
+          const uint64_t gtm = __ballot(g);
+          const uint64_t eqm = __ballot(fid == kid);                     // already in the frontier (set_union)
+          const uint64_t dupm = __ballot(cid == kid) & ((1ull << i) - 1ull);   // duplicate (std::unique)
           if (eqm == 0ull && dupm == 0ull) {
             live_mask |= 1ull << i;
-            if (lane == (int)i) myp = __popcll(ltm);
+            if (lane == (int)i) myp = f - (uint32_t)__popcll(gtm & vmask);
             rank_c += (kk < ckey) ? 1u : 0u;
-            below_f += (kk < fkey) ? 1u : 0u;
+            below_f += g ? 1u : 0u;
           }
         }
         const uint32_t nvalid = __popcll(live_mask);
@@ -1134,17 +1142,23 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
         const bool fl[RB] = {lane < (int)f, lane + 64 < (int)f};
         uint32_t myp = 0, rank_c = 0, below_f[RB] = {0, 0};
         uint64_t live_mask = 0;
+        // three 64-bit compares per candidate instead of eight (see the beam-64 kernel): ids decide equality, and the
+        // entries below a candidate are those not above it
+        const uint64_t vmask0 = __ballot(fl[0]), vmask1 = __ballot(fl[1]);
+        const uint32_t cid = (uint32_t)ckey, fid0 = (uint32_t)fkey[0], fid1 = (uint32_t)fkey[1];
         for (uint32_t i = 0; i < cc; i++) {
           const uint64_t kk = readlane64(ckey, (int)i);
-          const uint64_t lt0 = __ballot(fl[0] && fkey[0] < kk), lt1 = __ballot(fl[1] && fkey[1] < kk);
-          const uint64_t eq0 = __ballot(fl[0] && fkey[0] == kk), eq1 = __ballot(fl[1] && fkey[1] == kk);
-          const uint64_t dupm = __ballot(lane < (int)i && ckey == kk);
-          if ((eq0 | eq1) == 0ull && dupm == 0ull) {
+          const uint32_t kid = (uint32_t)kk;
+          const bool g0 = kk < fkey[0], g1 = kk < fkey[1];
+          const uint64_t gt0 = __ballot(g0), gt1 = __ballot(g1);
+          const uint64_t eqm = __ballot(fid0 == kid || fid1 == kid);
+          const uint64_t dupm = __ballot(cid == kid) & ((1ull << i) - 1ull);
+          if (eqm == 0ull && dupm == 0ull) {
             live_mask |= 1ull << i;
-            if (lane == (int)i) myp = __popcll(lt0) + __popcll(lt1);
+            if (lane == (int)i) myp = f - (uint32_t)__popcll(gt0 & vmask0) - (uint32_t)__popcll(gt1 & vmask1);
             rank_c += (kk < ckey) ? 1u : 0u;
-            below_f[0] += (kk < fkey[0]) ? 1u : 0u;
-            below_f[1] += (kk < fkey[1]) ? 1u : 0u;
+            below_f[0] += g0 ? 1u : 0u;
+            below_f[1] += g1 ? 1u : 0u;
           }
         }
         const uint32_t nvalid = __popcll(live_mask);
