@@ -332,21 +332,33 @@ __device__ __forceinline__ uint32_t gather_distances(const BSParams& P, const QR
 
 // The same for the survivors of TWO rows listed one after the other in Pl (row 1: Pl[0..split), row 2: the rest):
 // *c_split = size of C after the candidates of row 1 alone (the appends keep Pl order).
-template <int DT, int METRIC, int LPC, bool NCH1, int U>
+template <int DT, int METRIC, int LPC, bool NCH1, int U, bool BATCH_EMIT = false>
 __device__ __forceinline__ uint32_t gather_distances_split(const BSParams& P, const QReg<DT>& qreg, const uint4* qlds,
                                                            const uint32_t* Pl, uint32_t m, uint32_t split, uint32_t cutoff_ord,
                                                            uint64_t* C, uint32_t c, int lane, uint32_t* c_split) {
   const PointsView PV{P.points, P.pstride, P.nch, P.exact};
   uint32_t c1 = c;
-  gather_tile<DT, METRIC, LPC, NCH1, U>(PV, qreg, qlds, Pl, m, lane,
-    [&](bool has, uint32_t ci, uint32_t id, float dist) {
-      const uint32_t ord = f2ord(dist);
-      const bool pass = has && (ord < cutoff_ord);
-      const uint64_t pm = __ballot(pass);
-      if (pass) C[c + lanes_below(pm, lane)] = ((uint64_t)ord << 32) | id;
-      c += __popcll(pm);
-      c1 += __popcll(__ballot(pass && ci < split));
-    });
+  if constexpr (BATCH_EMIT) {
+    gather_tile<DT, METRIC, LPC, NCH1, U>(PV, qreg, qlds, Pl, m, lane,
+      [&](bool has, uint32_t ci, uint32_t id, float dist, uint64_t before) {
+        const uint32_t ord = f2ord(dist);
+        const bool pass = has && (ord < cutoff_ord);
+        const uint64_t pm = __ballot(pass);
+        if (pass) C[c + (uint32_t)__popcll(pm & before)] = ((uint64_t)ord << 32) | id;
+        c += __popcll(pm);
+        c1 += __popcll(__ballot(pass && ci < split));
+      });
+  } else {
+    gather_tile<DT, METRIC, LPC, NCH1, U>(PV, qreg, qlds, Pl, m, lane,
+      [&](bool has, uint32_t ci, uint32_t id, float dist) {
+        const uint32_t ord = f2ord(dist);
+        const bool pass = has && (ord < cutoff_ord);
+        const uint64_t pm = __ballot(pass);
+        if (pass) C[c + lanes_below(pm, lane)] = ((uint64_t)ord << 32) | id;
+        c += __popcll(pm);
+        c1 += __popcll(__ballot(pass && ci < split));
+      });
+  }
   *c_split = c1;
   return c;
 }
@@ -745,7 +757,7 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES_B64) beam_search_b64_
         PANN_STAMP(2);
         uint32_t c_after1 = c;
         if (both) {
-          if (m1 + m2) c = gather_distances_split<DT, METRIC, LPC, NCH1, PANN_GU>(P, qreg, qlds, Pl, m1 + m2, m1, cutoff_ord, C, c, lane, &c_after1);
+          if (m1 + m2) c = gather_distances_split<DT, METRIC, LPC, NCH1, PANN_GU, true>(P, qreg, qlds, Pl, m1 + m2, m1, cutoff_ord, C, c, lane, &c_after1);
         } else {
           if (m1) c = gather_distances<DT, METRIC, LPC, NCH1, PANN_GU>(P, qreg, qlds, Pl, m1, cutoff_ord, C, c, lane);
           c_after1 = c;
