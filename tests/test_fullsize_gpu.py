@@ -131,8 +131,9 @@ def test_hcnng_int8_mips_at_scale(oracle):
 def test_deep10m_vamana_at_full_size(oracle):
     """BASELINE config[2] at FULL size (DEEP-shaped 10M x 96 f32, Vamana R=64 L=128 alpha=1.05, 2 passes, built on the device):
     degree bound, well-formed rows, rows sorted by distance (sample), results sorted / duplicate-free with exact distances,
-    recall against exact ground truth, reproducibility.  (Real-valued floats: the device sums in another order than the CPU,
-    so the oracle comparison at this size is through recall, not bit for bit -- DESIGN.md "float order".)"""
+    recall against exact ground truth, reproducibility, and -- in exact-float-order mode -- a bit-exact oracle comparison of
+    sampled searches on the full graph.  (Real-valued floats: the fast path sums in another order than the CPU, so ITS oracle
+    comparison at this size is through recall -- DESIGN.md "float order".)"""
     n, d, nq, R, L = 10_000_000, 96, 2000, 64, 128
     X = datasets.deep_like(n, d, seed=1234); Q = datasets.deep_like(nq, d, seed=4321)
     ix = DeviceIndex(X, max_degree=R)
@@ -155,6 +156,20 @@ def test_deep10m_vamana_at_full_size(oracle):
     for i in range(len(some)):
         k = deg[some[i]]
         assert np.all(np.diff(dd[i, :k]) >= 0)                                     # neighbour lists sorted by distance
+    # Oracle comparison AT this size (the test made none): in exact-float-order mode the device sums like the CPU
+    # (left to right, unfused), so sampled queries on the full 10M-point graph must agree with the oracle bit for bit -- ids,
+    # distances, visited counts, comparison counts -- for external queries (beam 64, 128) and base-point queries (beam 128,
+    # the builder's search shape, k = 0)
+    from parlayann_amd._capi import check
+    check(ix._lib.pann_index_set_exact_float_order(ix._h, 1))
+    sample = np.arange(0, nq, 20)
+    for kw in (dict(queries=Q[sample], k=10, beam=64), dict(queries=Q[sample], k=10, beam=128),
+               dict(query_ids=rows[:100].astype(np.uint32), k=0, beam=128, out_k=10)):
+        g = ix.batch_search(**kw)
+        o = oracle.batch_search(X, G, **kw)
+        for f in ("ids", "dists", "visited_count", "dist_cmps"):
+            np.testing.assert_array_equal(o[f], g[f], err_msg=f"exact-float-order, {f}, {sorted(kw)}")
+    check(ix._lib.pann_index_set_exact_float_order(ix._h, 0))
     del G
     r = ix.batch_search(Q, k=10, beam=64)
     ids, dists = r["ids"], r["dists"]
