@@ -435,6 +435,12 @@ __device__ __forceinline__ void gather_tile(const PointsView& PV, const QReg<DT>
   if (s0 < m) gather_span<DT, METRIC, LPC, NCH1, U>(PV, qreg, qlds, Pl, m, s0, lane, emit);
 }
 
+#ifndef PANN_PRUNE_U_NCH1
+#define PANN_PRUNE_U_NCH1 2      /* candidate groups in flight per lane in gather_tile_multi: one-chunk rows */
+#endif
+#ifndef PANN_PRUNE_U_MULTI
+#define PANN_PRUNE_U_MULTI 1     /* ... rows of several chunks per lane (3 chunks of every group are requested together) */
+#endif
 // gather_tile for B query vectors at once: every candidate vector is fetched ONCE and scored against all of
 // them (robustPrune with several speculative picks per pass).  Query b: qreg[b] when the row is one chunk per
 // lane, else qlds[b * qstride4 ...].  Per (query, candidate) the arithmetic is exactly gather_tile's.
@@ -443,7 +449,7 @@ template <int DT, int METRIC, int LPC, bool NCH1, int B, typename Emit>
 __device__ __forceinline__ void gather_tile_multi(const PointsView& PV, const QReg<DT> (&qreg)[B], const uint4* qlds,
                                                   uint32_t qstride4, const uint32_t* Pl, uint32_t m, int lane, Emit&& emit) {
   constexpr int G = PANN_WAVE / LPC;
-  constexpr int U = NCH1 ? 2 : 1;
+  constexpr int U = NCH1 ? PANN_PRUNE_U_NCH1 : PANN_PRUNE_U_MULTI;
   const int grp = lane / LPC, sub = lane % LPC;
   for (uint32_t s0 = 0; s0 < m; s0 += G * U) {
     Acc<DT> acc[B][U];
