@@ -309,6 +309,9 @@ int pann_index_set_stream(pann_index* idx, void* stream, int use_private);
  *                   many trees (scratch: trees x n positions; default: as many as 2^31 positions allow)
  *   "gt_pieces"   : pann_bruteforce_knn -- the base is cut into this many pieces per 64-query tile (default: the count that
  *                   fills whole rounds of the 256 CUs best)
+ *   "locality_order": 1 (default) / 0 -- on tables beyond the Infinity Cache (> 1 GB of points) the Vamana builder launches the
+ *                   searches of a batch ordered by the locality cell of the inserted point (nearest of 256 pivots, one pass per
+ *                   handle); the graph does not depend on the launch order.  2: also on small tables and batches (tests)
  *   "filter_codes": 1 (default) / 0 -- the Vamana builder's L = 91..128 searches keep the lossy filter (beamSearch.h:52-59) as
  *                   12-bit class codes in LDS when every slot class has fewer than 4 095 members (n below ~16M), else as ids */
 int pann_index_set_option(pann_index* idx, const char* name, int64_t value);

@@ -71,6 +71,10 @@ struct pann_index {
   uint32_t vcap = 0;        // visited-list capacity used by the builder (grows on overflow)
   uint32_t dcap = 256;      // dropped-list capacity of the searches (pann_index_reserve_dropped; grows on overflow)
   uint32_t gt_pieces = 0;   // pann_index_set_option("gt_pieces"): pieces of the base per query tile in pann_bruteforce_knn (0 = auto)
+  DevBuf cell_buf;          // locality cell of every point (ensure_locality_cells)
+  uint32_t locality_groups = 32;    // ... whose pivots are grouped by their nearest of this many top pivots (0 / 1: no grouping)
+  uint32_t locality_pivots = 1024;   // cells of the locality order (pann_index_set_option("locality_pivots"): measurement knob)
+  int cells_state = 0;      // 0 not tried, 1 computed, -1 not worth it (table small enough to be cache resident) or switched off
   DevBuf code_rank, code_rows;   // filter-code table (filter_codes.hip): rank16[n], gcode[n][gstride]
   int codes_state = 0;      // 0 not tried, 1 available (rank16 built), -1 unavailable (a slot class has 4 095 or more members) or switched off
   DevBuf stage[12];      // staging for host-pointer calls
@@ -173,11 +177,64 @@ int upload_graph_rows(pann_index* idx, const uint32_t* h_rows, uint64_t m, const
   return PANN_OK;
 }
 
+// Locality cells: every point's nearest of 256 pivot points (evenly spaced ids), one dense top-1 pass per handle (~15 ms at
+// 10M x 96 f32).  The Vamana builder launches the searches of a batch in cell order (vamana_build.hip): a 10M-point launch reads
+// every row ~60 times, and queries that run side by side then read rows of the same few regions -- the 256 MiB Infinity Cache
+// holds what a few cells need, not what 200 000 queries scattered over the whole table need (search phase -20 %; the graph does
+// not depend on the launch order).  Only for tables beyond the cache.
+__global__ void gather_rows_kernel(const uint8_t* points, uint32_t pstride, uint64_t n, uint32_t npiv, uint8_t* out) {
+  const uint64_t src = (uint64_t)blockIdx.x * (n / npiv);
+  for (uint32_t b = threadIdx.x * 16; b < pstride; b += blockDim.x * 16)
+    *reinterpret_cast<uint4*>(out + (size_t)blockIdx.x * pstride + b) = *reinterpret_cast<const uint4*>(points + src * pstride + b);
+}
+// cell <- (group of the cell's pivot << 16) | cell: cells whose pivots share a nearest "top" pivot sort next to each other
+__global__ void group_cells_kernel(uint32_t* cell, uint64_t n, const uint32_t* pivot_group) {
+  const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (i < n) { const uint32_t c = cell[i]; cell[i] = (pivot_group[c] << 16) | c; }
+}
+int ensure_locality_cells(pann_index* idx) {
+  DeviceIndex& ix = idx->ix;
+  const uint32_t NPIV = idx->locality_pivots;
+  if (ix.cell || idx->cells_state != 0 || ix.exact) return PANN_OK;
+  static const bool off = ab_env("PANN_NO_LOCALITY") != nullptr;          // diagnostic A/B switch
+  const bool forced = ix.cell_min_batch < 4096;                           // pann_index_set_option("locality_order", 2): tests
+  if (off || ix.n < 2 * NPIV || (!forced && ((uint64_t)ix.n * ix.pstride < (1ull << 30) || ix.n < 256ull * NPIV))) {
+    idx->cells_state = -1; return PANN_OK;
+  }
+  hipStream_t st = idx->stream;
+  if (int rc = idx->stage[10].ensure((size_t)NPIV * ix.pstride)) return rc;
+  if (int rc = idx->stage[11].ensure((size_t)ix.n * 4)) return rc;                      // the distances (not kept)
+  if (int rc = idx->cell_buf.ensure((size_t)ix.n * 4 + 256)) return rc;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(NPIV), dim3(64), 0, st, ix.points, ix.pstride, ix.n, NPIV,
+                     idx->stage[10].as<uint8_t>());
+  PANN_HIP(hipGetLastError());
+  DeviceIndex pix = ix;                       // the pivots as a 256-point table; A rows = all base points, as external rows
+  pix.points = idx->stage[10].as<uint8_t>(); pix.n = NPIV; pix.graph = nullptr; pix.gcode = nullptr; pix.rank16 = nullptr; pix.cell = nullptr;
+  if (int rc = dense_topk_dev(pix, idx->ws2, st, ix.points, ix.pstride, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                              (uint32_t)((ix.n + 63) / 64), ix.n, NPIV, 1, 1, 0, idx->cell_buf.as<uint32_t>(),
+                              idx->stage[11].as<float>())) return rc;
+  if (idx->locality_groups > 1 && NPIV >= 4 * idx->locality_groups && NPIV <= 65536) {
+    // the pivots themselves by their nearest of the first `groups` pivots (a prefix of the pivot slab is a table too)
+    DeviceIndex gix = pix; gix.n = idx->locality_groups;
+    uint32_t* d_pg = idx->stage[11].as<uint32_t>();                       // [NPIV] group of every pivot, then [NPIV] distances
+    if (int rc = dense_topk_dev(gix, idx->ws2, st, pix.points, ix.pstride, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                (NPIV + 63) / 64, NPIV, gix.n, 1, 1, 0, d_pg, reinterpret_cast<float*>(d_pg + NPIV))) return rc;
+    hipLaunchKernelGGL(group_cells_kernel, dim3((uint32_t)((ix.n + 255) / 256)), dim3(256), 0, st, idx->cell_buf.as<uint32_t>(), ix.n, d_pg);
+    PANN_HIP(hipGetLastError());
+  }
+  PANN_HIP(hipStreamSynchronize(st));
+  idx->stage[11].release();
+  ix.cell = idx->cell_buf.as<uint32_t>();
+  idx->cells_state = 1;
+  return PANN_OK;
+}
+
 // The builder's L = 91..128 searches use the 12-bit filter-code table (filter_codes.hip) when every slot class is small
 // enough.  Called by the Vamana entry points before their searches: builds rank16 once per handle, and gcode from the
 // current graph whenever something outside the builder's row writers has changed the graph since.
 int ensure_filter_codes(pann_index* idx, uint32_t L) {
   DeviceIndex& ix = idx->ix;
+  if (int rc = ensure_locality_cells(idx)) return rc;     // (every Vamana entry point comes through here before its searches)
   if (L <= 90 || L > 128 || idx->codes_state < 0) return PANN_OK;
   if (ix.codes_valid) return PANN_OK;
   if (idx->codes_state == 0) {
@@ -303,7 +360,7 @@ void pann_index_destroy(pann_index* idx) {
   idx->ws.release(); idx->ws2.release(); idx->ws3.release(); idx->ws4.release();
   for (auto& s : idx->stage) s.release();
   idx->pin_in.release(); idx->pin_out.release();
-  idx->code_rank.release(); idx->code_rows.release();
+  idx->code_rank.release(); idx->code_rows.release(); idx->cell_buf.release();
   if (idx->own_stream) (void)hipStreamDestroy(idx->own_stream);
   delete idx;
 }
@@ -360,6 +417,7 @@ int64_t pann_index_get_option(const pann_index* idx, const char* name) {
   const std::string nm = name;
   if (nm == "forest_group") return idx->ix.forest_group;
   if (nm == "gt_pieces") return idx->gt_pieces;
+  if (nm == "locality_order") return idx->ix.cell ? 1 : 0;
   if (nm == "filter_codes") return idx->ix.codes_valid ? 1 : 0;         // are the class codes in step with the graph right now?
   return -1;
 }
@@ -378,6 +436,14 @@ int pann_index_set_option(pann_index* idx, const char* name, int64_t value) {
   if (value < 0 || value > 0x7FFFFFFF) { set_error("pann_index_set_option: value out of range"); return PANN_ERR_BAD_ARG; }
   if (nm == "forest_group") idx->ix.forest_group = (uint32_t)value;
   else if (nm == "gt_pieces") idx->gt_pieces = (uint32_t)value;
+  else if (nm == "locality_pivots") { idx->locality_pivots = std::max<uint32_t>(2, std::min<uint32_t>((uint32_t)value, 65536)); idx->ix.cell = nullptr; idx->cells_state = idx->cells_state < 0 ? idx->cells_state : 0; }
+  else if (nm == "locality_groups") { idx->locality_groups = (uint32_t)std::min<int64_t>(value, 4096); idx->ix.cell = nullptr; idx->cells_state = idx->cells_state < 0 ? idx->cells_state : 0; }
+  else if (nm == "locality_order") {        // 0: the builder launches a batch's searches in batch order
+    idx->ix.cell = nullptr;
+    idx->ix.cell_min_batch = value == 2 ? 64u : 4096u;       // 2: also on small tables and small batches (tests)
+    idx->cells_state = value ? ((idx->cell_buf.p && idx->cells_state == 1) ? 1 : 0) : -2;
+    if (idx->cells_state == 1) idx->ix.cell = idx->cell_buf.as<uint32_t>();
+  }
   else if (nm == "filter_codes") {          // 0: the beam-91..128 searches use the id table even where the class codes are available
     idx->ix.codes_valid = 0;
     idx->codes_state = value ? (idx->ix.rank16 ? 1 : 0) : -2;

@@ -104,6 +104,7 @@ struct BSParams {
   uint32_t prio_start;     // first block index that runs with raised issue priority (register-frontier beam-64 kernel)
   uint32_t hsplit;         // beam 65..128 in HBM mode: 0 whole table in HBM, 1 half, 2 three quarters of it in LDS
   uint32_t p24;            // ... whose LDS part holds planar 24-bit entries (n < 2^24 - 1)
+  const uint32_t* order;   // launch slot -> query (or null: identity).  Results do not depend on it: every output is indexed by the query
   const uint16_t* gcode;   // filter-code table (filter_codes.hip): codes of the neighbours, slot-aligned with the graph rows
   const uint16_t* rank16;  // ... and of every id (start points)
   uint64_t* dropped; uint32_t dcap;  // [nq][dcap] visited entries that left a non-full frontier
@@ -385,13 +386,14 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES) beam_search_kernel(B
   const uint32_t beam = P.beam;
   const uint32_t BIG_ORD = f2ord(2147483648.0f);  // (distanceType) numeric_limits<int>::max()  (:152)
 
-  uint32_t qi = blockIdx.x;
+  uint32_t slot = blockIdx.x;
   if constexpr (!HASH_LDS) {  // persistent: one filter slot per block, queries pulled from a counter
-    qi = 0;
-    if (lane == 0) qi = atomicAdd(P.work_counter, 1u);
-    qi = __builtin_amdgcn_readfirstlane(qi);
+    slot = 0;
+    if (lane == 0) slot = atomicAdd(P.work_counter, 1u);
+    slot = __builtin_amdgcn_readfirstlane(slot);
   }
-  while (qi < P.nq) {
+  while (slot < P.nq) {
+    const uint32_t qi = P.order ? P.order[slot] : slot;
     uint32_t* H = HASH_LDS ? Hl : P.hash_global + ((size_t)blockIdx.x << P.bits);
     // ---- filter init: hash_filter(1<<bits, -1) (:53) ----
     for (uint32_t i = lane; i < hsize; i += PANN_WAVE) hstore<HASH_LDS>(H, i, SENTINEL);
@@ -616,9 +618,9 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES) beam_search_kernel(B
     PANN_WSYNC();
     if constexpr (HASH_LDS) break;
     else {
-      qi = 0;
-      if (lane == 0) qi = atomicAdd(P.work_counter, 1u);
-      qi = __builtin_amdgcn_readfirstlane(qi);
+      slot = 0;
+      if (lane == 0) slot = atomicAdd(P.work_counter, 1u);
+      slot = __builtin_amdgcn_readfirstlane(slot);
     }
   }
 }
@@ -644,11 +646,11 @@ __global__ void __launch_bounds__(PANN_WAVE, PANN_MINWAVES_B64) beam_search_b64_
   const uint32_t hsize = 1u << P.bits, hmask = hsize - 1u;
   const uint32_t beam = P.beam;
   const uint32_t BIG_ORD = f2ord(2147483648.0f);            // (:152)
-  const uint32_t qi = blockIdx.x;
+  const uint32_t qi = P.order ? P.order[blockIdx.x] : blockIdx.x;
   // Blocks are dispatched in index order, so the highest indices start last and form the tail of the launch: they
   // get instruction-issue priority over the queries that are already under way (measured +1..3 % at 10K queries,
   // inside the box-to-box noise but never negative).
-  if (qi >= P.prio_start) __builtin_amdgcn_s_setprio(3);
+  if (blockIdx.x >= P.prio_start) __builtin_amdgcn_s_setprio(3);
 
   for (uint32_t i = lane; i < hsize; i += PANN_WAVE) H[i] = SENTINEL;       // :53
   const int64_t self = P.query_ids ? (int64_t)P.query_ids[qi] : -1;
@@ -940,13 +942,14 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
   const LdsPart Lp{reinterpret_cast<uint8_t*>(Hl), HASH_LDS ? 0u : (P.hsplit == 3 ? hsize : P.hsplit ? hsize - (hsize >> P.hsplit) : 0u), P.p24};
   // filter in LDS: one query per block.  Filter in HBM (16 KB of LDS would cap a CU at 8 queries): persistent
   // blocks, one table per block, queries pulled from a counter.
-  uint32_t qi = blockIdx.x;
+  uint32_t slot = blockIdx.x;
   if constexpr (!HASH_LDS) {
-    qi = 0;
-    if (lane == 0) qi = atomicAdd(P.work_counter, 1u);
-    qi = __builtin_amdgcn_readfirstlane(qi);
+    slot = 0;
+    if (lane == 0) slot = atomicAdd(P.work_counter, 1u);
+    slot = __builtin_amdgcn_readfirstlane(slot);
   }
-  while (qi < P.nq) {
+  while (slot < P.nq) {
+  const uint32_t qi = P.order ? P.order[slot] : slot;
   uint32_t* H = HASH_LDS ? Hl : P.hash_global + ((size_t)blockIdx.x << P.bits);
   const uint32_t hb = HASH_LDS ? 0u : P.hsplit;
   uint8_t* const P8 = reinterpret_cast<uint8_t*>(Hl);                    // CODES: 8-bit plane [hsize], then
@@ -1264,10 +1267,10 @@ __global__ void __launch_bounds__(PANN_WAVE) beam_search_b128_kernel(BSParams P)
     break;
   } else {
     PANN_WSYNC();
-    if (lane == 0) qi = atomicAdd(P.work_counter, 1u);
-    qi = __builtin_amdgcn_readfirstlane(qi);
+    if (lane == 0) slot = atomicAdd(P.work_counter, 1u);
+    slot = __builtin_amdgcn_readfirstlane(slot);
   }
-  }   // while (qi < P.nq)
+  }   // while (slot < P.nq)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1454,6 +1457,7 @@ int launch_beam_search(const DeviceIndex& ix, const SearchArgs& a, void* ws, siz
   P.hsplit = p.b128_hbm ? p.hsplit : 0u;
   P.p24 = p.b128_hbm ? p.p24 : 0u;
   P.gcode = ix.gcode; P.rank16 = ix.rank16;
+  P.order = a.order;
   P.hash_global = p.hash_lds ? nullptr : (uint32_t*)(w + 256 + (size_t)a.nq * p.dcap * 8);
   P.out = a.out;
   P.stamps = nullptr;

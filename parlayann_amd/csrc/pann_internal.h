@@ -45,6 +45,10 @@ struct DeviceIndex {
   const uint16_t* rank16 = nullptr;   // [n]
   uint16_t* gcode = nullptr;          // [n][gstride]
   uint32_t codes_valid = 0;
+  // locality cell of every point (nearest of LOCALITY_PIVOTS pivots), for the order in which a batch's searches are launched
+  // (vamana_build.hip: queries that run side by side then read rows of the same few regions); null = not computed
+  const uint32_t* cell = nullptr;     // [n]
+  uint32_t cell_min_batch = 4096;     // batches below this many searches keep the batch order
 };
 
 // The kernels come in two families (PANN_LAYOUT_SWITCH): rows that are ONE 16-byte chunk per lane with 8 / 16 / 32
@@ -61,6 +65,7 @@ struct SearchArgs {  // one batched beam search, everything device resident
   int starts_per_query = 0;                  // starts is nq x nstarts (beamSearchRandom)
   int64_t k, beam, limit, degree_limit; double cut;
   uint32_t dcap = 256;                       // dropped-list entries per query (pann_index_reserve_dropped)
+  const uint32_t* order = nullptr;           // device, nq entries: launch slot -> query index (a permutation); null = identity
   pann_search_out out;
 };
 

@@ -353,6 +353,16 @@ __global__ void __launch_bounds__(PANN_WAVE) prune_count_tail_kernel(GreedyArgs 
   if (lane == 0) A.dcmps[oi] += live;
 }
 
+// launch order of a batch's searches: slots sorted by (locality cell of the inserted point, position in the batch)
+__global__ void order_keys_kernel(const uint32_t* batch, const uint32_t* cell, uint32_t m, uint64_t* keys) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) keys[i] = ((uint64_t)cell[batch[i]] << 32) | i;
+}
+__global__ void order_from_keys_kernel(const uint64_t* keys, uint32_t m, uint32_t* order) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) order[i] = (uint32_t)keys[i];
+}
+
 __global__ void fixed_stride_setup_kernel(uint64_t* cand_base, uint32_t* seg_begin, uint32_t m,
                                           uint32_t cand_stride, uint32_t seg_stride) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -649,11 +659,13 @@ int vamana_search_prune_dev(const DeviceIndex& ix, Workspace& ws, Workspace& sea
     const uint32_t seg_stride = vcap + ix.gstride;
     const uint64_t total_keys = (uint64_t)m * seg_stride;
     if (total_keys >= 0xFFFFFFF0ull) { set_error("vamana insert: batch too large"); return PANN_ERR_BAD_ARG; }
-    const size_t stmp = seg_sort_temp_bytes((uint32_t)total_keys, m);
-    uint32_t *d_start, *d_vis_ids, *d_vis_cnt, *d_dcs, *d_seg, *d_send, *d_rcnt, *d_dc;
+    const bool ordered = ix.cell != nullptr && m >= ix.cell_min_batch;          // launch the searches in locality order (api.hip: ensure_locality_cells)
+    const size_t stmp = std::max(seg_sort_temp_bytes((uint32_t)total_keys, m), ordered ? sort_temp_bytes(m) : (size_t)0);
+    uint32_t *d_start, *d_vis_ids, *d_vis_cnt, *d_dcs, *d_seg, *d_send, *d_rcnt, *d_dc, *d_order;
     float* d_vis_d; uint64_t *d_base, *ka, *kb; void* d_tmp;
     auto layout = [&](Bump& b) {
       d_start = b.take<uint32_t>(4);
+      d_order = b.take<uint32_t>(ordered ? m : 1);
       d_vis_ids = b.take<uint32_t>((size_t)m * vcap); d_vis_d = b.take<float>((size_t)m * vcap);
       d_vis_cnt = b.take<uint32_t>(m); d_dcs = b.take<uint32_t>(m);
       d_base = b.take<uint64_t>(m); d_seg = b.take<uint32_t>(m); d_send = b.take<uint32_t>(m);
@@ -673,6 +685,14 @@ int vamana_search_prune_dev(const DeviceIndex& ix, Workspace& ws, Workspace& sea
     sa.out = pann_search_out{};
     sa.out.visited_ids = d_vis_ids; sa.out.visited_dists = d_vis_d; sa.out.visited_cap = vcap;
     sa.out.visited_count = d_vis_cnt; sa.out.dist_cmps = d_dcs;
+    if (ordered) {      // (ka / kb / d_tmp are the prune's scratch: free until the searches are done)
+      hipLaunchKernelGGL(order_keys_kernel, dim3((m + 255) / 256), dim3(256), 0, st, d_batch, ix.cell, m, ka);
+      size_t tb = stmp + 16;
+      PANN_HIP(rocprim::radix_sort_keys(d_tmp, tb, ka, kb, m, 0, 64, st));
+      hipLaunchKernelGGL(order_from_keys_kernel, dim3((m + 255) / 256), dim3(256), 0, st, kb, m, d_order);
+      PANN_HIP(hipGetLastError());
+      sa.order = d_order;
+    }
     if (int rc = search_ws.ensure(search_workspace_bytes(ix, sa))) return rc;
     if (int rc = launch_beam_search(ix, sa, search_ws.buf, search_ws.bytes, st)) return rc;
     uint32_t status = 0;

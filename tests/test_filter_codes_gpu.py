@@ -104,3 +104,19 @@ def test_tables_too_large_for_12_bit_codes_fall_back_to_ids():
     r = ix.batch_search(queries=X[batch[:100]], k=5, beam=128, starts=(int(batch[0]),))
     assert np.isin(r["ids"][:, 0], batch).all()                  # what a search reaches are inserted points (a one-batch star graph)
     ix.close()
+
+
+@pytest.mark.parametrize("dtype,d,R,L", [(np.uint8, 128, 32, 64), (np.float32, 96, 48, 128), (np.float16, 128, 32, 200)])
+def test_launch_order_of_a_batch_does_not_change_the_graph(oracle, dtype, d, R, L):
+    """round 3: on large tables the builder launches the searches of a batch in locality order (nearest of 256 pivots); forced
+    here on a small table for the beam-64, beam-128 (code table) and generic kernels: the graph is the oracle's, as before"""
+    n = 30000
+    X = datasets.sift_like(n, d, seed=31, dtype=np.float32).astype(dtype)
+    Go, so = oracle.vamana_build(X, R, L, 1.2, num_passes=2, seed=6)
+    ix = DeviceIndex(X, max_degree=R)
+    ix.set_option("locality_order", 2)
+    st = ix.vamana_build(R, L, 1.2, num_passes=2, seed=6)
+    assert ix.get_option("locality_order") == 1
+    np.testing.assert_array_equal(_norm(Go), _norm(ix.get_graph()))
+    assert int(so[0]) == st.search_dist_cmps and int(so[1]) == st.prune_dist_cmps and int(so[2]) == st.visited_total
+    ix.close()
