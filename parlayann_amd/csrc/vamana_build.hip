@@ -47,13 +47,14 @@ struct PruneArgs {
   uint32_t* dcmps;               // [m] distance_comps (accumulated)
   int add_out_nbrs;
   uint32_t m;
+  const uint32_t* order;         // launch slot -> owner index (or null): owners that run side by side then share candidate rows
 };
 
 // candidates := given (id,dist) list  U  {(G[p][i], d(G[p][i], p))}   (:70-77)
 template <int DT, int METRIC, int LPC, bool NCH1>
 __global__ void __launch_bounds__(PANN_WAVE) prune_keys_kernel(PruneArgs A) {
   const int lane = threadIdx.x;
-  const uint32_t oi = blockIdx.x;
+  const uint32_t oi = A.order ? A.order[blockIdx.x] : blockIdx.x;
   __shared__ uint32_t Pl[PANN_WAVE];
   extern __shared__ __align__(16) uint8_t smem[];
   uint4* qlds = reinterpret_cast<uint4*>(smem);
@@ -108,6 +109,7 @@ struct GreedyArgs {
   uint32_t* cnt_out;                          // [m] (or null)
   uint32_t* graph; uint32_t gstride;          // direct write of the owner's row when rows_out == null
   uint16_t* gcode; const uint16_t* rank16;    // ... with the filter codes of the new row (filter_codes.hip), or null
+  const uint32_t* order;                      // launch slot -> owner index (or null)
   uint32_t* dcmps;
   uint32_t m;
   uint32_t kcap;                              // lists up to this many keys are pruned in LDS
@@ -128,7 +130,7 @@ __device__ __forceinline__ void st_key(uint64_t* p, uint64_t v) {
 template <int DT, int METRIC, int LPC, bool NCH1>
 __global__ void __launch_bounds__(PANN_WAVE, PANN_PRUNE_MINWAVES) prune_greedy_kernel(GreedyArgs A) {
   const int lane = threadIdx.x;
-  const uint32_t oi = blockIdx.x;
+  const uint32_t oi = A.order ? A.order[blockIdx.x] : blockIdx.x;
   __shared__ uint32_t Pl[PANN_WAVE];    // live candidate ids of the current tile
   __shared__ uint32_t Pp[PANN_WAVE];    // their positions in the segment
   __shared__ float Pd[PANN_WAVE];       // their distance to p  (dist_pprime)
@@ -323,7 +325,7 @@ template <int DT, int METRIC, int LPC, bool NCH1>
 __global__ void __launch_bounds__(PANN_WAVE) prune_count_tail_kernel(GreedyArgs A) {
   // distance_comps of the last pick's inner loop == number of live candidates after it
   const int lane = threadIdx.x;
-  const uint32_t oi = blockIdx.x;
+  const uint32_t oi = A.order ? A.order[blockIdx.x] : blockIdx.x;
   const uint32_t p = A.owners[oi];
   const uint64_t* K = A.keys + A.seg_begin[oi];
   const uint32_t n = A.seg_end[oi] - A.seg_begin[oi];
@@ -712,10 +714,11 @@ int vamana_search_prune_dev(const DeviceIndex& ix, Workspace& ws, Workspace& sea
     pa.graph = ix.graph; pa.gstride = ix.gstride; pa.max_deg = ix.max_deg;
     pa.owners = d_batch; pa.cand_ids = d_vis_ids; pa.cand_dists = d_vis_d; pa.cand_base = d_base; pa.cand_cnt = d_vis_cnt;
     pa.seg_begin = d_seg; pa.seg_end = d_send; pa.dcmps = d_dc; pa.add_out_nbrs = 1; pa.m = m;
+    pa.order = ordered ? d_order : nullptr;
     GreedyArgs ga{};
     ga.pv = pa.pv; ga.dbytes = ix.dbytes; ga.owners = d_batch; ga.alpha = alpha; ga.R = R;
     ga.rows_out = d_rows; ga.rows_stride = R; ga.cnt_out = d_rcnt; ga.graph = nullptr; ga.gstride = ix.gstride;
-    ga.dcmps = d_dc; ga.m = m;
+    ga.dcmps = d_dc; ga.m = m; ga.order = pa.order;
     if (int rc = run_prune(ix, pa, ga, ka, kb, (uint32_t)total_keys, d_tmp, stmp, st, seg_stride)) return rc;
     PANN_HIP(hipStreamSynchronize(st));
     const auto t2 = now_();
