@@ -688,6 +688,10 @@ __device__ __forceinline__ void gt_lds_barrier() { asm volatile("s_waitcnt lgkmc
 // survivor queues of the queued selection (gt_select_queued below): 16 rows per wave, GT_QCAP keys each
 constexpr uint32_t GT_QCAP = 64;       // >= 4 x 16: what one tile can offer a row
 constexpr size_t GT_QUEUE_BYTES = 4 * (size_t)DT_AW * GT_QCAP * 8;      // per workgroup: 32 KB
+#ifndef PANN_GT_FLUSH_EVERY
+#define PANN_GT_FLUSH_EVERY 32
+#endif
+constexpr uint32_t GT_FLUSH_EVERY = PANN_GT_FLUSH_EVERY;               // tiles between two flushes of all waves of a workgroup (a power of two)
 template <int NR>
 struct GtSel {
   uint64_t R[4][NR];     // R[r] = row 4q + r, right-aligned in 16*NR places (the leading ones hold key 0, which nothing displaces):
@@ -854,29 +858,34 @@ __device__ __forceinline__ void gt_flush(GtSel<NR>& S, const uint64_t* Qw /* thi
 // flush (a single call site: inlined into each of the 16 groups the flush made the tile loop a 13 000-instruction body; a real
 // loop around one copy of the append code made hipcc copy the lists at every back edge and cost 2 ms).  After a flush the queues
 // are empty and a row receives at most 4 x 16 keys from one tile, so pass 2 always fits (GT_QCAP >= 64).
-template <int NR>
-__device__ __forceinline__ void gt_select_queued(GtSel<NR>& S, const float (&dist)[4][4], const uint32_t (&bid)[4], const uint32_t (&skip)[4],
+// NEG: d holds NEGATED distances (the matrix-core kernel computes 2 a.b - (|a|^2 + |b|^2) = -dist with one add and one fma per
+// element and no sign flip of the accumulators; the test is d >= -tau, the sign modifier of the compare is free).
+template <int NR, bool NEG = false>
+__device__ __forceinline__ void gt_select_queued(GtSel<NR>& S, const float (&d)[4][4], const uint32_t (&bid)[4], const uint32_t (&skip)[4],
                                                  uint32_t pplace, uint32_t* gtau_mine, uint32_t nsplit, uint64_t* Qw, int lane) {
   const int q = lane >> 4;
-  bool any = false;
+  auto pass = [&](int r, int t) -> bool { return NEG ? (d[r][t] >= -S.tauf[r]) : (d[r][t] <= S.tauf[r]); };
+  auto dist = [&](int r, int t) -> float { return NEG ? -d[r][t] : d[r][t]; };
+  // the common case -- no survivor in the wave's 16 x 64 distances -- is 16 compares whose masks are OR-ed on the scalar side
+  uint64_t anym = 0ull;
 #pragma unroll
   for (int r = 0; r < 4; r++)
 #pragma unroll
-    for (int t = 0; t < 4; t++) any = any || (dist[r][t] <= S.tauf[r]);
-  if (!__any(any)) return;
+    for (int t = 0; t < 4; t++) anym |= __ballot(pass(r, t));
+  if (anym == 0ull) return;
   const uint32_t below = (1u << (lane & 15)) - 1u;
   uint32_t left = 0;                                             // wave-uniform: bit 4r + t
 #pragma unroll
   for (int r = 0; r < 4; r++) {
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-      const bool p = dist[r][t] <= S.tauf[r] && bid[t] != SENTINEL && bid[t] != skip[r];
+      const bool p = pass(r, t) && bid[t] != SENTINEL && bid[t] != skip[r];
       const uint64_t m = __ballot(p);
       if (m == 0ull) continue;                                   // wave-uniform
       const uint32_t f = (uint32_t)(m >> (16 * q)) & 0xFFFFu;    // the offers of my quarter
       const uint32_t n = __popc(f);
       if (__any(S.cnt[r] + n > GT_QCAP)) { left |= 1u << (4 * r + t); continue; }
-      if (p) Qw[(size_t)(q * 4 + r) * GT_QCAP + S.cnt[r] + __popc(f & below)] = make_key(dist[r][t], bid[t]);
+      if (p) Qw[(size_t)(q * 4 + r) * GT_QCAP + S.cnt[r] + __popc(f & below)] = make_key(dist(r, t), bid[t]);
       S.cnt[r] += n;
     }
   }
@@ -887,9 +896,9 @@ __device__ __forceinline__ void gt_select_queued(GtSel<NR>& S, const float (&dis
 #pragma unroll
     for (int t = 0; t < 4; t++) {
       if (!((left >> (4 * r + t)) & 1u)) continue;
-      const bool p = dist[r][t] <= S.tauf[r] && bid[t] != SENTINEL && bid[t] != skip[r];      // (the threshold has just tightened)
+      const bool p = pass(r, t) && bid[t] != SENTINEL && bid[t] != skip[r];      // (the threshold has just tightened)
       const uint32_t f = (uint32_t)(__ballot(p) >> (16 * q)) & 0xFFFFu;
-      if (p) Qw[(size_t)(q * 4 + r) * GT_QCAP + S.cnt[r] + __popc(f & below)] = make_key(dist[r][t], bid[t]);
+      if (p) Qw[(size_t)(q * 4 + r) * GT_QCAP + S.cnt[r] + __popc(f & below)] = make_key(dist(r, t), bid[t]);
       S.cnt[r] += __popc(f);
     }
   }
@@ -963,6 +972,9 @@ __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, cons
   float an[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) an[r] = An[wave * DT_AW + q * 4 + r];
+  float nan[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) nan[r] = -an[r];
   const uint32_t pplace = 16u * NR - A.m + (A.m + A.nsplit - 1) / A.nsplit - 1;   // list place of the ceil(m/nsplit)-th best
   const uint32_t tau_period = GT_TAU_PERIOD * ((A.nsplit + 7) / 8);
   uint32_t tau_wait = tau_period;
@@ -1053,13 +1065,30 @@ __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, cons
       if constexpr (METRIC == PANN_L2) return (an[r] + bn[t]) - 2.0f * acc[t][r];
       else return -acc[t][r];
     };
-    float dist[4][4];
+    if constexpr (QUEUED) {
+      // negated distances: -(|a|^2 + |b|^2) + 2 a.b -- the same value as the formula above with the sign flipped (negation is
+      // exact and rounding is symmetric), without a sign flip per accumulator
+      float nd[4][4];
 #pragma unroll
-    for (int r = 0; r < 4; r++)
+      for (int r = 0; r < 4; r++)
 #pragma unroll
-      for (int t = 0; t < 4; t++) dist[r][t] = distf(r, t);
-    if constexpr (QUEUED) gt_select_queued<NR>(S, dist, bid, skip, pplace, gtau_mine, A.nsplit, Qw, lane);
-    else gt_select<NR>(S, dist, bid, skip, pplace, gtau_mine, A.nsplit, lane);
+        for (int t = 0; t < 4; t++) {
+          if constexpr (METRIC == PANN_L2) nd[r][t] = __builtin_fmaf(2.0f, acc[t][r], nan[r] - bn[t]);
+          else nd[r][t] = acc[t][r];
+        }
+      gt_select_queued<NR, true>(S, nd, bid, skip, pplace, gtau_mine, A.nsplit, Qw, lane);
+      // all four waves of the workgroup also empty their queues at the SAME tiles, every GT_FLUSH_EVERY-th: a wave that flushes
+      // alone keeps its three siblings at the tile barrier for the whole flush (8 / 32 / 64 / 128 tiles: 10.3 / 10.1 / 10.15 /
+      // 10.25 ms, never: 11.5 ms at 10K x 1M, k = 100)
+      if ((i & (GT_FLUSH_EVERY - 1)) == GT_FLUSH_EVERY - 1) gt_flush<NR>(S, Qw, pplace, gtau_mine, A.nsplit, lane);
+    } else {
+      float dist[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) dist[r][t] = distf(r, t);
+      gt_select<NR>(S, dist, bid, skip, pplace, gtau_mine, A.nsplit, lane);
+    }
     gt_lds_barrier();
   }
   if constexpr (QUEUED) gt_flush<NR>(S, Qw, pplace, gtau_mine, A.nsplit, lane);
