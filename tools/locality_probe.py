@@ -32,12 +32,13 @@ rng = np.random.default_rng(5)
 batch = rng.choice(n, m, replace=False).astype(np.uint32)
 
 # locality key: nearest of 4096 pivots, pivots grouped by their nearest of 64 top pivots
-piv = rng.choice(n, 4096, replace=False)
+NP = int(os.environ.get("PIV", 4096))
+piv = rng.choice(n, NP, replace=False)
 pix = DeviceIndex(X[piv], max_degree=4)
 near, _ = pix.bruteforce_knn(X[batch], 1)
 top = DeviceIndex(X[piv[:64]], max_degree=4)
 ptop, _ = top.bruteforce_knn(X[piv], 1)
-key = ptop[near[:, 0], 0].astype(np.int64) * 4096 + near[:, 0]
+key = ptop[near[:, 0], 0].astype(np.int64) * NP + near[:, 0]
 srt = batch[np.argsort(key, kind="stable")]
 cpx = m // 8
 b = np.arange(m)
