@@ -320,6 +320,25 @@ typedef _Float16 mf_half8 __attribute__((ext_vector_type(8)));
 typedef __bf16 mf_bf8 __attribute__((ext_vector_type(8)));
 typedef float mf_float4 __attribute__((ext_vector_type(4)));
 
+template <bool BF>
+__device__ __forceinline__ float sumsq16(uint4 v) {
+  float ss = 0.f;
+  if constexpr (BF) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const float lo = bf16_lo(w[i]), hi = bf16_hi(w[i]); ss = fmaf(lo, lo, ss); ss = fmaf(hi, hi, ss); }
+  } else {
+    mf_half8 h; __builtin_memcpy(&h, &v, 16);
+#pragma unroll
+    for (int i = 0; i < 8; i++) { const float f = (float)h[i]; ss = fmaf(f, f, ss); }
+  }
+  return ss;
+}
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains the vector memory counter, which would wait
+// for the tile requested two iterations ahead at every tile (measured: 2.6 us per tile, the loaded HBM latency)
+__device__ __forceinline__ void gt_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // BF == false: IEEE binary16 operands (v_mfma_f32_16x16x32_f16); BF == true: bfloat16 (v_mfma_f32_16x16x32_bf16).
 // Both accumulate in f32; products of two-byte values are exact in f32, so integer-valued data gives exact sums.
 template <int METRIC, bool BF>
@@ -393,45 +412,165 @@ __global__ void __launch_bounds__(256) dense_topk_mfma_f16_kernel(DenseArgs A) {
   const uint32_t a_valid = A.a_ids ? A.pstride : A.dbytes;
   if (nseg == 1) stage_rows(At, An, 0, a_rowptr, a_valid, na_tile);
 
-  // register double buffer of the B tile (single-segment rows): thread (r0 = tid >> 4, c = tid & 15) holds chunk c of rows
-  // r0, r0 + 16, r0 + 32, r0 + 48
-  uint4 pre[4];
-  auto load_pre = [&](uint64_t bt, uint32_t nrows) {
-    const int r0 = tid >> 4, c = tid & 15;
+  // epilogue of one tile: acc[t][r] = a(row wave*16 + 4*(lane>>4) + r) . b(column t*16 + (lane & 15)) -> distance, top-m update
+  auto epilogue = [&](mf_float4 (&acc)[4], uint32_t nb_tile, uint32_t* Kw, bool k_aliases_bt) {
+  // ---- epilogue: C[row = 4*(lane>>4) + r][col = lane&15] of tile t -> distance, top-m update ----
+  const int q = lane >> 4;
+  if (lane_lists) {
+    if (k_aliases_bt) __syncthreads();                    // every wave is done reading Bt: reuse it as K
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int r = r0 + 16 * k;
-      pre[k] = make_uint4(0, 0, 0, 0);
-      if (r < (int)nrows) {
-        const uint64_t id = A.b_ids ? (uint64_t)A.b_ids[bt + r] : (bt + r);
-        pre[k] = load16_guarded(A.points + id * A.pstride, c * 16, A.pstride);
+    for (int r = 0; r < 4; r++) {
+      const uint32_t row = q * 4 + r, ar = wave * DT_AW + row;
+      const float an = An[ar];
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const uint32_t bc = t * 16 + (lane & 15);
+        const uint32_t bid = Bid[bc];
+        float dist;
+        if constexpr (METRIC == PANN_L2) dist = (an + Bn[bc]) - 2.0f * acc[t][r];
+        else dist = -acc[t][r];
+        bool ok = (bc < nb_tile) && (ar < na_tile);
+        if (A.exclude_same_id) ok = ok && (bid != Aid[ar]);
+        Kw[row * MF_KS + t * 17 + (lane & 15)] = ok ? f2ord(dist) : 0xFFFFFFFFu;
       }
     }
-  };
-  auto store_pre = [&](uint32_t nrows) {
-    const int r0 = tid >> 4, c = tid & 15;
+    wave_lds_sync();
+    {
+      const uint32_t* krow = Kw + (lane & 15) * MF_KS + (lane >> 4) * 17;
+      const uint32_t* idq = Bid + (lane >> 4) * 16;
+      uint64_t tau = TL[15];
+      uint32_t bits = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int r = r0 + 16 * k;
-      const uint4 v = pre[k];
-      *reinterpret_cast<uint4*>(Bt + (size_t)r * DT_BSTRIDE + c * 16) = v;
-      float ss = 0.f;
-      if constexpr (BF) {
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int i = 0; i < 4; i++) { const float lo = bf16_lo(w[i]), hi = bf16_hi(w[i]); ss = fmaf(lo, lo, ss); ss = fmaf(hi, hi, ss); }
-      } else {
-        mf_half8 h; __builtin_memcpy(&h, &v, 16);
-#pragma unroll
-        for (int i = 0; i < 8; i++) { const float f = (float)h[i]; ss = fmaf(f, f, ss); }
+      for (int j = 0; j < 16; j++) bits |= (krow[j] <= (uint32_t)(tau >> 32) && krow[j] != 0xFFFFFFFFu) ? (1u << j) : 0u;
+      while (bits) {
+        const int j = __ffs(bits) - 1;
+        bits &= bits - 1;
+        const uint64_t x = ((uint64_t)krow[j] << 32) | idq[j];
+        if (x < tau) { tm_chain_insert(TL, x); tau = TL[15]; }
       }
-      ss = group_sum<16>(ss);
-      if (c == 0) Bn[r] = ss;
     }
-    (void)nrows;
-  };
-  if (nseg == 1 && bs < be) load_pre(bs, (uint32_t)min((uint64_t)DT_B, be - bs));
-
+    return;                                               // (K aliasing Bt: the next tile's barrier protects it)
+  }
+  // m > 16 (ground truth): the 16 distances of a lane (4 rows x 4 columns) are tested against register copies of their rows'
+  // m-th best FIRST -- after the lists have warmed up nearly every tile ends here with one ballot; only a tile with a
+  // survivor walks the (row, column) pairs and inserts (the lists live in LDS, one wave-wide shift per insert)
+  {
+    uint64_t key[4][4];
+    bool pass[4][4];
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const uint32_t ar = wave * DT_AW + q * 4 + r;          // this lane's A row for register r
+      const float an = An[ar];
+      const uint64_t tau = (lists + (size_t)ar * A.mcap)[A.m - 1];
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const uint32_t bc = t * 16 + (lane & 15);
+        const uint32_t bid = Bid[bc];
+        float dist;
+        if constexpr (METRIC == PANN_L2) dist = (an + Bn[bc]) - 2.0f * acc[t][r];
+        else dist = -acc[t][r];
+        key[r][t] = make_key(dist, bid);
+        bool ok = (bc < nb_tile) && (ar < na_tile);
+        if (A.exclude_same_id) ok = ok && (bid != Aid[ar]);
+        pass[r][t] = ok && key[r][t] < tau;
+        any = any || pass[r][t];
+      }
+    }
+    if (__any(any)) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          uint64_t mask = __ballot(pass[r][t]);
+          while (mask) {
+            const int L = __ffsll((unsigned long long)mask) - 1;
+            const uint32_t klo = __builtin_amdgcn_readlane((uint32_t)key[r][t], L);
+            const uint32_t khi = __builtin_amdgcn_readlane((uint32_t)(key[r][t] >> 32), L);
+            const uint64_t x = ((uint64_t)khi << 32) | klo;
+            mask &= mask - 1;
+            uint64_t* list = lists + (size_t)(wave * DT_AW + (L >> 4) * 4 + r) * A.mcap;
+            if (x < list[A.m - 1]) list_insert(list, A.mcap, x, lane);
+          }
+        }
+      }
+    }
+  }
+    };
+  if (nseg == 1) {
+    // ---- single-segment rows (every HCNNG leaf build on two-byte points): the staging of dense_gt_mfma_kernel (round 3) ----
+    // unconditional clamped loads (a position beyond the piece re-reads its last row and is masked by nb_tile), the ids ONE tile
+    // ahead of the rows and the rows one tile ahead of the multiply, barriers that order LDS only (__syncthreads() also drains
+    // the vector memory counter: it waited for the tile it had just requested), K in its own region so that no barrier stands
+    // between the multiply and the epilogue: two LDS barriers per tile instead of four full ones.
+    uint32_t* Ks = reinterpret_cast<uint32_t*>(lists + (size_t)DT_A * A.mcap) + wave * (DT_AW * MF_KS);
+    const int r0 = tid >> 4, c = tid & 15;
+    const uint32_t nchunk = A.pstride >> 4;
+    const bool cvalid = (uint32_t)c < nchunk;
+    const uint8_t* cbase = A.points + min((uint32_t)c, nchunk - 1u) * 16u;
+    const uint64_t last = be - 1;                                       // (bs < be inside)
+    uint32_t id_cur[4], id_nxt[4];
+    uint4 prer[4];
+    auto load_ids = [&](uint64_t bt, uint32_t (&ids)[4]) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint64_t pos = min(bt + (uint64_t)(r0 + 16 * k), last);
+        ids[k] = A.b_ids ? A.b_ids[pos] : (uint32_t)pos;
+      }
+    };
+    auto load_rows = [&](const uint32_t (&ids)[4]) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) prer[k] = *reinterpret_cast<const uint4*>(cbase + (uint64_t)ids[k] * A.pstride);
+    };
+    auto store_rows = [&](const uint32_t (&ids)[4], uint64_t bt) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int r = r0 + 16 * k;
+        const uint4 v = cvalid ? prer[k] : make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(Bt + (size_t)r * DT_BSTRIDE + c * 16) = v;
+        const float ss = group_sum<16>(sumsq16<BF>(v));
+        if (c == 0) { Bn[r] = ss; Bid[r] = bt + (uint64_t)r < be ? ids[k] : SENTINEL; }
+      }
+    };
+    if (bs < be) {
+      load_ids(bs, id_cur);
+      load_rows(id_cur);
+      load_ids(bs + DT_B, id_nxt);
+    }
+    for (uint64_t bt = bs; bt < be; bt += DT_B) {
+      const uint32_t nb_tile = (uint32_t)min((uint64_t)DT_B, be - bt);
+      gt_lds_barrier();                                                 // the previous tile's multiply has read Bt
+      store_rows(id_cur, bt);
+      load_rows(id_nxt);                                                // tile bt + 64 (its ids arrived a tile ago)
+#pragma unroll
+      for (int k = 0; k < 4; k++) id_cur[k] = id_nxt[k];
+      load_ids(bt + 2 * DT_B, id_nxt);                                  // ids of tile bt + 128
+      gt_lds_barrier();
+      mf_float4 acc[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) acc[t] = mf_float4{0.f, 0.f, 0.f, 0.f};
+      const uint32_t ksteps = A.pstride / 64;
+      for (uint32_t ks = 0; ks < ksteps; ks++) {
+        const uint32_t koff = ks * 64 + (lane >> 4) * 16;
+        if constexpr (BF) {
+          const mf_bf8 af = *reinterpret_cast<const mf_bf8*>(At + (size_t)(wave * DT_AW + (lane & 15)) * DT_BSTRIDE + koff);
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            const mf_bf8 bf = *reinterpret_cast<const mf_bf8*>(Bt + (size_t)(t * 16 + (lane & 15)) * DT_BSTRIDE + koff);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[t], 0, 0, 0);
+          }
+        } else {
+          const mf_half8 af = *reinterpret_cast<const mf_half8*>(At + (size_t)(wave * DT_AW + (lane & 15)) * DT_BSTRIDE + koff);
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            const mf_half8 bf = *reinterpret_cast<const mf_half8*>(Bt + (size_t)(t * 16 + (lane & 15)) * DT_BSTRIDE + koff);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[t], 0, 0, 0);
+          }
+        }
+      }
+      epilogue(acc, nb_tile, Ks, false);
+    }
+  } else
   for (uint64_t bt = bs; bt < be; bt += DT_B) {
     const uint32_t nb_tile = (uint32_t)min((uint64_t)DT_B, be - bt);
     auto b_rowptr = [&](int r) -> const uint8_t* {
@@ -443,20 +582,12 @@ __global__ void __launch_bounds__(256) dense_topk_mfma_f16_kernel(DenseArgs A) {
     for (int t = 0; t < 4; t++) acc[t] = mf_float4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     if (tid < DT_B) { Bid[tid] = tid < (int)nb_tile ? (A.b_ids ? A.b_ids[bt + tid] : (uint32_t)(bt + tid)) : SENTINEL; Bn[tid] = 0.f; }
-    if (nseg > 1 && tid < DT_A) An[tid] = 0.f;
+    if (tid < DT_A) An[tid] = 0.f;
     __syncthreads();
     for (uint32_t sg = 0; sg < nseg; sg++) {
       if (sg > 0) __syncthreads();
-      if (nseg == 1) {
-        // rows of one 256-byte segment: this tile's rows were requested while the previous tile was being multiplied
-        // (pre[]), the next tile's are requested now -- with k = 100 the per-row lists leave room for ONE workgroup per CU,
-        // so without this every tile paid a full, exposed HBM round trip (10K x 1M: 50 ms of kernel time, 2/3 of it waiting)
-        store_pre(nb_tile);
-        if (bt + DT_B < be) load_pre(bt + DT_B, (uint32_t)min((uint64_t)DT_B, be - (bt + DT_B)));
-      } else {
-        stage_rows(Bt, Bn, sg, b_rowptr, A.pstride, nb_tile);
-        stage_rows(At, An, sg, a_rowptr, a_valid, na_tile);
-      }
+      stage_rows(Bt, Bn, sg, b_rowptr, A.pstride, nb_tile);
+      stage_rows(At, An, sg, a_rowptr, a_valid, na_tile);
       __syncthreads();
       const uint32_t ksteps = min((uint32_t)DT_SEG, A.pstride - sg * DT_SEG) / 64;   // 32 halves per MFMA
       for (uint32_t ks = 0; ks < ksteps; ks++) {
@@ -478,88 +609,7 @@ __global__ void __launch_bounds__(256) dense_topk_mfma_f16_kernel(DenseArgs A) {
         }
       }
     }
-    // ---- epilogue: C[row = 4*(lane>>4) + r][col = lane&15] of tile t -> distance, top-m update ----
-    const int q = lane >> 4;
-    if (lane_lists) {
-      __syncthreads();                                      // every wave is done reading Bt: reuse it as K
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const uint32_t row = q * 4 + r, ar = wave * DT_AW + row;
-        const float an = An[ar];
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-          const uint32_t bc = t * 16 + (lane & 15);
-          const uint32_t bid = Bid[bc];
-          float dist;
-          if constexpr (METRIC == PANN_L2) dist = (an + Bn[bc]) - 2.0f * acc[t][r];
-          else dist = -acc[t][r];
-          bool ok = (bc < nb_tile) && (ar < na_tile);
-          if (A.exclude_same_id) ok = ok && (bid != Aid[ar]);
-          Kw[row * MF_KS + t * 17 + (lane & 15)] = ok ? f2ord(dist) : 0xFFFFFFFFu;
-        }
-      }
-      wave_lds_sync();
-      {
-        const uint32_t* krow = Kw + (lane & 15) * MF_KS + (lane >> 4) * 17;
-        const uint32_t* idq = Bid + (lane >> 4) * 16;
-        uint64_t tau = TL[15];
-        uint32_t bits = 0;
-#pragma unroll
-        for (int j = 0; j < 16; j++) bits |= (krow[j] <= (uint32_t)(tau >> 32) && krow[j] != 0xFFFFFFFFu) ? (1u << j) : 0u;
-        while (bits) {
-          const int j = __ffs(bits) - 1;
-          bits &= bits - 1;
-          const uint64_t x = ((uint64_t)krow[j] << 32) | idq[j];
-          if (x < tau) { tm_chain_insert(TL, x); tau = TL[15]; }
-        }
-      }
-      continue;                                             // the next tile's barrier protects K
-    }
-    // m > 16 (ground truth): the 16 distances of a lane (4 rows x 4 columns) are tested against register copies of their rows'
-    // m-th best FIRST -- after the lists have warmed up nearly every tile ends here with one ballot; only a tile with a
-    // survivor walks the (row, column) pairs and inserts (the lists live in LDS, one wave-wide shift per insert)
-    {
-      uint64_t key[4][4];
-      bool pass[4][4];
-      bool any = false;
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const uint32_t ar = wave * DT_AW + q * 4 + r;          // this lane's A row for register r
-        const float an = An[ar];
-        const uint64_t tau = (lists + (size_t)ar * A.mcap)[A.m - 1];
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-          const uint32_t bc = t * 16 + (lane & 15);
-          const uint32_t bid = Bid[bc];
-          float dist;
-          if constexpr (METRIC == PANN_L2) dist = (an + Bn[bc]) - 2.0f * acc[t][r];
-          else dist = -acc[t][r];
-          key[r][t] = make_key(dist, bid);
-          bool ok = (bc < nb_tile) && (ar < na_tile);
-          if (A.exclude_same_id) ok = ok && (bid != Aid[ar]);
-          pass[r][t] = ok && key[r][t] < tau;
-          any = any || pass[r][t];
-        }
-      }
-      if (__any(any)) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-#pragma unroll
-          for (int t = 0; t < 4; t++) {
-            uint64_t mask = __ballot(pass[r][t]);
-            while (mask) {
-              const int L = __ffsll((unsigned long long)mask) - 1;
-              const uint32_t klo = __builtin_amdgcn_readlane((uint32_t)key[r][t], L);
-              const uint32_t khi = __builtin_amdgcn_readlane((uint32_t)(key[r][t] >> 32), L);
-              const uint64_t x = ((uint64_t)khi << 32) | klo;
-              mask &= mask - 1;
-              uint64_t* list = lists + (size_t)(wave * DT_AW + (L >> 4) * 4 + r) * A.mcap;
-              if (x < list[A.m - 1]) list_insert(list, A.mcap, x, lane);
-            }
-          }
-        }
-      }
-    }
+    epilogue(acc, nb_tile, Kw, true);
   }
   __syncthreads();
   if (lane_lists) {   // rank merge of the four quarter lists of every row (as in dense_topk_kernel); At + Bt hold the lists
@@ -622,21 +672,6 @@ constexpr int GT_BT_BYTES = DT_B * GT_BSTRIDE;
 __device__ __forceinline__ uint32_t gt_swz(uint32_t row, uint32_t off) { return row * GT_BSTRIDE + (off ^ ((row & 15u) << 4)); }
 constexpr uint32_t GT_TAU_PERIOD = 8;      // tiles between two looks at what the other pieces of a row have published
 
-template <bool BF>
-__device__ __forceinline__ float sumsq16(uint4 v) {
-  float ss = 0.f;
-  if constexpr (BF) {
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int i = 0; i < 4; i++) { const float lo = bf16_lo(w[i]), hi = bf16_hi(w[i]); ss = fmaf(lo, lo, ss); ss = fmaf(hi, hi, ss); }
-  } else {
-    mf_half8 h; __builtin_memcpy(&h, &v, 16);
-#pragma unroll
-    for (int i = 0; i < 8; i++) { const float f = (float)h[i]; ss = fmaf(f, f, ss); }
-  }
-  return ss;
-}
-
 // |row|^2 of every point, summed like the staging code of the kernel above (16 lanes x 16 bytes, f32 fma chain per lane,
 // butterfly over the 16 lanes)
 template <bool BF>
@@ -678,10 +713,6 @@ __device__ unsigned long long gt_counters[8];
 #else
 #define GT_COUNT(i, v) do { } while (0)
 #endif
-
-// workgroup barrier that orders LDS traffic only: __syncthreads() also drains the vector memory counter, which would wait
-// for the tile requested two iterations ahead at every tile (measured: 2.6 us per tile, the loaded HBM latency)
-__device__ __forceinline__ void gt_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // selection state of a wave in the ground-truth / leaf kernels: lists, float thresholds, what was published.
 // NR registers of 16 places per row: 8 (m <= 128, ground truth) or 1 (m <= 16: HCNNG leaves, small-k ground truth).
@@ -1453,7 +1484,8 @@ int dense_topk_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, const u
   else if (ix.dtype == PANN_BF16 && ix.exact && ix.metric == PANN_L2) CALL_DENSE(PANN_BF16, PANN_L2);
   else if (ix.dtype == PANN_BF16 && ix.exact) CALL_DENSE(PANN_BF16, PANN_MIPS);
   else {
-    const size_t lds2 = (size_t)(DT_A + DT_B) * DT_BSTRIDE + (DT_A + DT_B) * 8 + (size_t)DT_A * mcap * 8;
+    const size_t lds2 = (size_t)(DT_A + DT_B) * DT_BSTRIDE + (DT_A + DT_B) * 8 + (size_t)DT_A * mcap * 8 +
+                        4 * (size_t)DT_AW * 68 * 4;       // + the epilogue's transposition scratch K (single-segment rows keep it apart from the B tile)
 #define CALL_MFMA(MT, BF)                                                                               \
   do {                                                                                                   \
     auto kern = dense_topk_mfma_f16_kernel<MT, BF>;                                                      \
