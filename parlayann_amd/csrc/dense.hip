@@ -1011,8 +1011,11 @@ __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, cons
   uint32_t tau_wait = tau_period;
   uint32_t* gtau_mine = gtau + (a0 + wave * DT_AW + q * 4) * A.nsplit + blockIdx.y;
 
-  uint4 pre0, pre1, pre2, pre3;
-  float pn = 0.f;
+  // Two tiles are in flight in registers (pa*, pb*), each requested TWO iterations before it is written to LDS: with one set
+  // an iteration could not be shorter than the latency of the L2 miss behind it (round 3: 1.9 us per tile, whatever the
+  // instruction stream did -- one 16 KB tile outstanding per workgroup = 2.9 TB/s at that latency).
+  uint4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3;
+  float pan = 0.f, pbn = 0.f;
   // Branch-free, mask-free staging: rows are 16-byte aligned, a multiple of 16 bytes long and zero padded
   // (pann_index_create), so every lane reads a clamped row unconditionally; a row index beyond the piece re-reads the
   // piece's last row and is labelled SENTINEL (never offered to a list).  Lanes whose 16-byte column lies beyond the row
@@ -1022,39 +1025,45 @@ __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, cons
   const bool cvalid = (uint32_t)c < nchunk;
   const uint8_t* cbase = A.points + min((uint32_t)c, nchunk - 1u) * 16u;
   const uint32_t last_row = (uint32_t)(be - 1);                    // be > bs wherever a load is issued; positions are 32-bit
-  // (four named registers, not an array: as an array the compiler kept the tile in scratch memory)
-  auto load_pre = [&](uint64_t bt) {          // requests only: nothing here may depend on the loaded values
-    pre0 = *reinterpret_cast<const uint4*>(cbase + (uint64_t)min((uint32_t)bt + (uint32_t)r0, last_row) * A.pstride);
-    pre1 = *reinterpret_cast<const uint4*>(cbase + (uint64_t)min((uint32_t)bt + (uint32_t)r0 + 16u, last_row) * A.pstride);
-    pre2 = *reinterpret_cast<const uint4*>(cbase + (uint64_t)min((uint32_t)bt + (uint32_t)r0 + 32u, last_row) * A.pstride);
-    pre3 = *reinterpret_cast<const uint4*>(cbase + (uint64_t)min((uint32_t)bt + (uint32_t)r0 + 48u, last_row) * A.pstride);
-    if (METRIC == PANN_L2) pn = bnorm[min((uint32_t)bt + (uint32_t)lane, last_row)];       // every wave: no branch around a load
-  };
-  auto store_pre = [&](int buf, uint64_t bt) {
+  // (named registers, not arrays or a struct passed by reference: those the compiler kept in scratch memory)
+#define GT_LOAD_PRE(v0, v1, v2, v3, vn, bt_)          /* requests only: nothing here may depend on the loaded values */              \
+  do {                                                                                                                              \
+    const uint32_t b_ = (uint32_t)(bt_) + (uint32_t)r0;                                                                             \
+    v0 = *reinterpret_cast<const uint4*>(cbase + (uint64_t)min(b_, last_row) * A.pstride);                                          \
+    v1 = *reinterpret_cast<const uint4*>(cbase + (uint64_t)min(b_ + 16u, last_row) * A.pstride);                                    \
+    v2 = *reinterpret_cast<const uint4*>(cbase + (uint64_t)min(b_ + 32u, last_row) * A.pstride);                                    \
+    v3 = *reinterpret_cast<const uint4*>(cbase + (uint64_t)min(b_ + 48u, last_row) * A.pstride);                                    \
+    if (METRIC == PANN_L2) vn = bnorm[min((uint32_t)(bt_) + (uint32_t)lane, last_row)];    /* every wave: no branch around a load */ \
+  } while (0)
+  auto store_tile = [&](const uint4& v0, const uint4& v1, const uint4& v2, const uint4& v3, float vn, int buf, uint64_t bt) {
     if (cvalid) {
       uint8_t* dst = Bt0 + buf * GT_BT_BYTES + gt_swz((uint32_t)r0, (uint32_t)c * 16u);      // rows r0 + 16 k share r0's swizzle
-      *reinterpret_cast<uint4*>(dst) = pre0;
-      *reinterpret_cast<uint4*>(dst + 16 * GT_BSTRIDE) = pre1;
-      *reinterpret_cast<uint4*>(dst + 32 * GT_BSTRIDE) = pre2;
-      *reinterpret_cast<uint4*>(dst + 48 * GT_BSTRIDE) = pre3;
+      *reinterpret_cast<uint4*>(dst) = v0;
+      *reinterpret_cast<uint4*>(dst + 16 * GT_BSTRIDE) = v1;
+      *reinterpret_cast<uint4*>(dst + 32 * GT_BSTRIDE) = v2;
+      *reinterpret_cast<uint4*>(dst + 48 * GT_BSTRIDE) = v3;
     }
     if (tid < DT_B)
-      Bm[buf * DT_B + tid] = make_float2(pn, __uint_as_float(bt + tid < be ? (uint32_t)(bt + tid) : SENTINEL));
+      Bm[buf * DT_B + tid] = make_float2(vn, __uint_as_float(bt + tid < be ? (uint32_t)(bt + tid) : SENTINEL));
   };
+  // tile bt -> LDS buffer buf from its register set, then the set is refilled with tile bt + 2 tiles
+  auto stage_a = [&](int buf, uint64_t bt) { store_tile(pa0, pa1, pa2, pa3, pan, buf, bt); GT_LOAD_PRE(pa0, pa1, pa2, pa3, pan, bt + 2 * DT_B); };
+  auto stage_b = [&](int buf, uint64_t bt) { store_tile(pb0, pb1, pb2, pb3, pbn, buf, bt); GT_LOAD_PRE(pb0, pb1, pb2, pb3, pbn, bt + 2 * DT_B); };
   if (!cvalid) {
 #pragma unroll
     for (int k = 0; k < 8; k++)
       *reinterpret_cast<uint4*>(Bt0 + (k >> 2) * GT_BT_BYTES + gt_swz((uint32_t)(r0 + 16 * (k & 3)), (uint32_t)c * 16u)) = make_uint4(0, 0, 0, 0);
   }
   if (ntile > 0) {           // (an empty piece issues no loads: last_row is meaningless there)
-    load_pre(bs); store_pre(0, bs);
-    load_pre(bs + DT_B);
+    GT_LOAD_PRE(pa0, pa1, pa2, pa3, pan, bs); store_tile(pa0, pa1, pa2, pa3, pan, 0, bs);
+    GT_LOAD_PRE(pa0, pa1, pa2, pa3, pan, bs + DT_B);
+    GT_LOAD_PRE(pb0, pb1, pb2, pb3, pbn, bs + 2 * DT_B);
   }
   gt_lds_barrier();
 
-  for (uint32_t i = 0; i < ntile; i++) {
+  // one tile: `buf` holds it, `stage` writes tile i+1 (requested two iterations ago) and requests tile i+3 into the same registers
+  auto tile_step = [&](uint32_t i, const int buf, auto&& stage) {
     const uint64_t bt = bs + (uint64_t)i * DT_B;
-    const int buf = (int)(i & 1);
     if (A.nsplit > 1 && --tau_wait == 0) {
       tau_wait = tau_period;
       gt_sel_refresh<NR>(S, gtau + a0 * A.nsplit, (uint32_t)(wave * DT_AW + q * 4), na_tile, A.nsplit);
@@ -1062,8 +1071,7 @@ __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, cons
     // No branches around these: beyond the last tile they re-stage the piece's last row (clamped loads, SENTINEL labels)
     // into the buffer nobody reads again -- with conditional staging the compiler waited for the requests just made
     // before the first MFMA.
-    store_pre(buf ^ 1, bt + DT_B);                             // tile i+1 (requested one iteration ago) -> the other buffer
-    load_pre(bt + 2 * DT_B);                                   // tile i+2 -> registers, in flight during this tile's math
+    stage(buf ^ 1, bt + DT_B);                                 // tile i+1 -> the other buffer; tile i+3 -> registers, in flight during two tiles' math
     mf_float4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) acc[t] = mf_float4{0.f, 0.f, 0.f, 0.f};
@@ -1121,9 +1129,15 @@ __global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, cons
       gt_select<NR>(S, dist, bid, skip, pplace, gtau_mine, A.nsplit, lane);
     }
     gt_lds_barrier();
+  };
+  // (an odd tile count runs one more step on a tile of SENTINEL labels: no branch around the second half's loads)
+  for (uint32_t i = 0; i < ntile; i += 2) {
+    tile_step(i, 0, stage_a);
+    tile_step(i + 1, 1, stage_b);
   }
   if constexpr (QUEUED) gt_flush<NR>(S, Qw, pplace, gtau_mine, A.nsplit, lane);
   gt_sel_write<NR>(S, A.partial + ((a0 + wave * DT_AW + q * 4) * A.nsplit + blockIdx.y) * A.m, A.m, A.nsplit, lane);
+#undef GT_LOAD_PRE
 }
 
 // ---- the same kernel for the types whose contraction stays on the VALU (north_star: no MFMA for int8/uint8; f32 has none

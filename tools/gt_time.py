@@ -17,6 +17,8 @@ X = datasets.sift1m_like(n, 128, seed=1234, dtype=dt)
 Q = datasets.sift1m_like(nq, 128, seed=4321, dtype=dt)
 ix = DeviceIndex(X, max_degree=8)
 k = int(sys.argv[4]) if len(sys.argv) > 4 else 100
+if os.environ.get("GT_PIECES"):
+    ix.set_option("gt_pieces", int(os.environ["GT_PIECES"]))
 ix.bruteforce_knn(Q[:256], k)
 best = 1e9
 for _ in range(3):
