@@ -954,7 +954,10 @@ __device__ __forceinline__ void gt_sel_write(const GtSel<NR>& S, uint64_t* parti
 }
 
 template <int METRIC, bool BF, int NR>
-__global__ void __launch_bounds__(256, 2) dense_gt_mfma_kernel(DenseArgs A, const float* __restrict__ bnorm, uint32_t* gtau) {
+#ifndef PANN_GT_WGS
+#define PANN_GT_WGS 2     /* workgroups per CU the register budget allows (3: measurement builds; the k > 16 lists then spill) */
+#endif
+__global__ void __launch_bounds__(256, PANN_GT_WGS) dense_gt_mfma_kernel(DenseArgs A, const float* __restrict__ bnorm, uint32_t* gtau) {
   extern __shared__ __align__(16) uint8_t smem[];
   uint8_t* Bt0 = smem;                                                    // [2][64][GT_BSTRIDE], slots swizzled (gt_swz)
   float2* Bm = reinterpret_cast<float2*>(smem + 2 * GT_BT_BYTES);         // [2][64] (|b|^2, id bits)
@@ -1392,8 +1395,9 @@ bool dense_gt_eligible(const DeviceIndex& ix, uint32_t m, bool b_ids, bool segme
   const bool twobyte = ix.dtype == PANN_F16 || ix.dtype == PANN_BF16;
   return twobyte ? ix.pstride <= 256 : ix.pstride <= 512;        // matrix cores: one 256-byte segment; VALU register tile: two
 }
-static size_t dense_gt_lds(const DeviceIndex& ix) {
-  if (ix.dtype == PANN_F16 || ix.dtype == PANN_BF16) return GT_LDS_BYTES + GT_QUEUE_BYTES;      // matrix-core kernel: + the survivor queues
+static size_t dense_gt_lds(const DeviceIndex& ix, uint32_t m) {
+  if (ix.dtype == PANN_F16 || ix.dtype == PANN_BF16)       // matrix-core kernel: + the survivor queues (k > 16: one list register per row inserts at once)
+    return GT_LDS_BYTES + (m > 16 ? GT_QUEUE_BYTES : 0);
   const size_t nseg = (ix.pstride + DT_SEG - 1) / DT_SEG;
   return GT_LDS_BYTES + (size_t)DT_A * (nseg * DT_SEG + 16);
 }
@@ -1420,7 +1424,7 @@ static int dense_gt_pick(const DeviceIndex& ix, uint32_t m, F&& f) {
 // workgroups of the ground-truth launch that are resident at once (for the caller's choice of nsplit)
 uint32_t dense_gt_slots(const DeviceIndex& ix, uint32_t m) {
   if (!dense_gt_eligible(ix, m, false, false, 0)) return 256;
-  const size_t lds = dense_gt_lds(ix);
+  const size_t lds = dense_gt_lds(ix, m);
   const int nb = dense_gt_pick(ix, m, [&](auto kern) -> int {
     int v = 0;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1468,7 +1472,7 @@ int dense_topk_dev(const DeviceIndex& ix, Workspace& ws, hipStream_t st, const u
       else if (ix.dtype == PANN_U8) hipLaunchKernelGGL(row_norms_i8_kernel<PANN_U8>, ng, dim3(256), 0, st, ix.points, ix.pstride, nnorm, (int*)d_norm);
       else if (ix.dtype == PANN_I8) hipLaunchKernelGGL(row_norms_i8_kernel<PANN_I8>, ng, dim3(256), 0, st, ix.points, ix.pstride, nnorm, (int*)d_norm);
     }
-    const size_t glds = dense_gt_lds(ix);
+    const size_t glds = dense_gt_lds(ix, m);
     dense_gt_pick(ix, m, [&](auto kern) -> int {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds);
       using norm_t = std::conditional_t<std::is_invocable_v<decltype(kern), DenseArgs, const float*, uint32_t*>, const float*, const int*>;
