@@ -844,6 +844,7 @@ template <int NR>
 __device__ __forceinline__ void gt_flush(GtSel<NR>& S, const uint64_t* Qw /* this wave's [16][GT_QCAP] */, uint32_t pplace,
                                          uint32_t* gtau_mine, uint32_t nsplit, int lane) {
   const int q = lane >> 4;
+  GT_COUNT(4, 1);                                                // flushes
   wave_lds_sync();                                               // the appends of this wave are visible to its reads
 #pragma unroll
   for (int r = 0; r < 4; r++) {
@@ -898,21 +899,28 @@ __device__ __forceinline__ void gt_select_queued(GtSel<NR>& S, const float (&d)[
   auto pass = [&](int r, int t) -> bool { return NEG ? (d[r][t] >= -S.tauf[r]) : (d[r][t] <= S.tauf[r]); };
   auto dist = [&](int r, int t) -> float { return NEG ? -d[r][t] : d[r][t]; };
   // the common case -- no survivor in the wave's 16 x 64 distances -- is 16 compares whose masks are OR-ed on the scalar side
-  uint64_t anym = 0ull;
+  // (per row set r first: a wave-tile with a survivor has one in 1.2 of its 4 row sets on average -- 2.4 of 16 groups -- and the
+  //  other row sets are skipped on their mask, a scalar test, instead of 4 x (6 vector instructions + a branch) each)
+  uint64_t rowm[4];
 #pragma unroll
-  for (int r = 0; r < 4; r++)
+  for (int r = 0; r < 4; r++) {
+    rowm[r] = 0ull;
 #pragma unroll
-    for (int t = 0; t < 4; t++) anym |= __ballot(pass(r, t));
-  if (anym == 0ull) return;
+    for (int t = 0; t < 4; t++) rowm[r] |= __ballot(pass(r, t));
+  }
+  if ((rowm[0] | rowm[1] | rowm[2] | rowm[3]) == 0ull) return;
+  GT_COUNT(1, 1);                                                // wave-tiles with a survivor of the float test
   const uint32_t below = (1u << (lane & 15)) - 1u;
   uint32_t left = 0;                                             // wave-uniform: bit 4r + t
 #pragma unroll
   for (int r = 0; r < 4; r++) {
+    if (rowm[r] == 0ull) continue;                               // wave-uniform, scalar
 #pragma unroll
     for (int t = 0; t < 4; t++) {
       const bool p = pass(r, t) && bid[t] != SENTINEL && bid[t] != skip[r];
       const uint64_t m = __ballot(p);
       if (m == 0ull) continue;                                   // wave-uniform
+      GT_COUNT(5, 1); GT_COUNT(3, __popcll(m));                  // (row set, column block) groups with an offer; keys offered
       const uint32_t f = (uint32_t)(m >> (16 * q)) & 0xFFFFu;    // the offers of my quarter
       const uint32_t n = __popc(f);
       if (__any(S.cnt[r] + n > GT_QCAP)) { left |= 1u << (4 * r + t); continue; }
@@ -1118,7 +1126,16 @@ __global__ void __launch_bounds__(256, PANN_GT_WGS) dense_gt_mfma_kernel(DenseAr
           if constexpr (METRIC == PANN_L2) nd[r][t] = __builtin_fmaf(2.0f, acc[t][r], nan[r] - bn[t]);
           else nd[r][t] = acc[t][r];
         }
+#ifdef PANN_GT_DIAG_NOSELECT      /* timing diagnostic: no selection at all (results are wrong) */
+      { float mx = nd[0][0];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+          for (int t = 0; t < 4; t++) mx = fmaxf(mx, nd[r][t]);
+        S.R[0][0] += (uint64_t)__float_as_uint(mx + __uint_as_float(bid[0])); }
+#else
       gt_select_queued<NR, true>(S, nd, bid, skip, pplace, gtau_mine, A.nsplit, Qw, lane);
+#endif
       // all four waves of the workgroup also empty their queues at the SAME tiles, every GT_FLUSH_EVERY-th: a wave that flushes
       // alone keeps its three siblings at the tile barrier for the whole flush (8 / 32 / 64 / 128 tiles: 10.3 / 10.1 / 10.15 /
       // 10.25 ms, never: 11.5 ms at 10K x 1M, k = 100)
@@ -1131,7 +1148,11 @@ __global__ void __launch_bounds__(256, PANN_GT_WGS) dense_gt_mfma_kernel(DenseAr
         for (int t = 0; t < 4; t++) dist[r][t] = distf(r, t);
       gt_select<NR>(S, dist, bid, skip, pplace, gtau_mine, A.nsplit, lane);
     }
+#ifdef PANN_GT_DIAG_NOBARRIER     /* timing diagnostic: the waves of a workgroup run free (results are wrong) */
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     gt_lds_barrier();
+#endif
   };
   // (an odd tile count runs one more step on a tile of SENTINEL labels: no branch around the second half's loads)
   for (uint32_t i = 0; i < ntile; i += 2) {

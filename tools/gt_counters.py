@@ -22,5 +22,7 @@ lib.pann_debug_gt_counters(out, 1)
 ix.bruteforce_knn(Q, k)
 lib.pann_debug_gt_counters(out, 1)
 c = list(out)
-print(f"nsplit={os.environ.get('PANN_GT_NSPLIT', 'auto')}: wave-tiles {c[0]}, "
-      f"rounds {c[2]} ({c[2] / max(c[0], 1):.3f}/wave-tile)")
+wt = max(c[0], 1)
+print(f"wave-tiles {c[0]}; with a survivor {c[1]} ({c[1] / wt:.3f}); (row set, column block) groups with an offer {c[5]} ({c[5] / wt:.3f}/wave-tile); "
+      f"keys offered {c[3]} ({c[3] / wt:.3f}/wave-tile, {c[3] / nq:.0f}/query); flushes {c[4]} ({c[4] / wt:.4f}/wave-tile); "
+      f"insert rounds {c[2]} ({c[2] / wt:.3f}/wave-tile, {c[3] / max(c[2], 1):.2f} keys/round)")
