@@ -901,12 +901,12 @@ __device__ __forceinline__ void gt_select_queued(GtSel<NR>& S, const float (&d)[
   // the common case -- no survivor in the wave's 16 x 64 distances -- is 16 compares whose masks are OR-ed on the scalar side
   // (per row set r first: a wave-tile with a survivor has one in 1.2 of its 4 row sets on average -- 2.4 of 16 groups -- and the
   //  other row sets are skipped on their mask, a scalar test, instead of 4 x (6 vector instructions + a branch) each)
+  //  the row set's test is ONE compare of its best of the four column blocks: max3 + max, then a compare, instead of four compares)
   uint64_t rowm[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    rowm[r] = 0ull;
-#pragma unroll
-    for (int t = 0; t < 4; t++) rowm[r] |= __ballot(pass(r, t));
+    const float best = NEG ? fmaxf(fmaxf(fmaxf(d[r][0], d[r][1]), d[r][2]), d[r][3]) : fminf(fminf(fminf(d[r][0], d[r][1]), d[r][2]), d[r][3]);
+    rowm[r] = __ballot(NEG ? (best >= -S.tauf[r]) : (best <= S.tauf[r]));
   }
   if ((rowm[0] | rowm[1] | rowm[2] | rowm[3]) == 0ull) return;
   GT_COUNT(1, 1);                                                // wave-tiles with a survivor of the float test
