@@ -915,18 +915,24 @@ __device__ __forceinline__ void gt_select_queued(GtSel<NR>& S, const float (&d)[
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     if (rowm[r] == 0ull) continue;                               // wave-uniform, scalar
+    // the four column blocks of the row set together: ONE wave-uniform decision (does every quarter's queue take all its
+    // offers?) instead of two per block -- every such decision is a vector compare the scalar unit has to wait for
+    bool p[4]; uint32_t f[4]; uint32_t n = 0;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-      const bool p = pass(r, t) && bid[t] != SENTINEL && bid[t] != skip[r];
-      const uint64_t m = __ballot(p);
-      if (m == 0ull) continue;                                   // wave-uniform
-      GT_COUNT(5, 1); GT_COUNT(3, __popcll(m));                  // (row set, column block) groups with an offer; keys offered
-      const uint32_t f = (uint32_t)(m >> (16 * q)) & 0xFFFFu;    // the offers of my quarter
-      const uint32_t n = __popc(f);
-      if (__any(S.cnt[r] + n > GT_QCAP)) { left |= 1u << (4 * r + t); continue; }
-      if (p) Qw[(size_t)(q * 4 + r) * GT_QCAP + S.cnt[r] + __popc(f & below)] = make_key(dist(r, t), bid[t]);
-      S.cnt[r] += n;
+      p[t] = pass(r, t) && bid[t] != SENTINEL && bid[t] != skip[r];
+      f[t] = (uint32_t)(__ballot(p[t]) >> (16 * q)) & 0xFFFFu;   // the offers of my quarter
+      n += __popc(f[t]);
     }
+    GT_COUNT(5, 1); GT_COUNT(3, n);                              // row sets with an offer; keys offered (lane 0's quarter)
+    if (__any(S.cnt[r] + n > GT_QCAP)) { left |= 0xFu << (4 * r); continue; }
+    uint32_t pos = S.cnt[r];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      if (p[t]) Qw[(size_t)(q * 4 + r) * GT_QCAP + pos + __popc(f[t] & below)] = make_key(dist(r, t), bid[t]);
+      pos += __popc(f[t]);
+    }
+    S.cnt[r] = pos;
   }
   if (left == 0) return;
   gt_flush<NR>(S, Qw, pplace, gtau_mine, nsplit, lane);
