@@ -1430,9 +1430,12 @@ static size_t dense_gt_lds(const DeviceIndex& ix, uint32_t m) {
 }
 template <typename F>
 static int dense_gt_pick(const DeviceIndex& ix, uint32_t m, F&& f) {
-  const bool l2 = ix.metric == PANN_L2, small = m <= 16;
+  // list registers per row: 1 (k <= 16), 7 (k <= 112: the usual ground truth, k = 100 -- an insert step is one register shorter
+  // than with 8 and the kernel holds 8 registers less) or 8
+  const bool l2 = ix.metric == PANN_L2, small = m <= 16, mid = m <= 112;
 #define GT_MF(BF)                                                                                                                   \
   (small ? (l2 ? f(dense_gt_mfma_kernel<PANN_L2, BF, 1>) : f(dense_gt_mfma_kernel<PANN_MIPS, BF, 1>))                                \
+   : mid ? (l2 ? f(dense_gt_mfma_kernel<PANN_L2, BF, 7>) : f(dense_gt_mfma_kernel<PANN_MIPS, BF, 7>))                                \
          : (l2 ? f(dense_gt_mfma_kernel<PANN_L2, BF, 8>) : f(dense_gt_mfma_kernel<PANN_MIPS, BF, 8>)))
 #define GT_VA(DT)                                                                                                                   \
   (small ? (l2 ? f(dense_gt_valu_kernel<DT, PANN_L2, 1>) : f(dense_gt_valu_kernel<DT, PANN_MIPS, 1>))                                \

@@ -73,6 +73,7 @@ def test_bruteforce_knn(oracle, dtype, metric, d, k):
     ("l2", 128, 65, 5000, 1, 2), ("l2", 128, 128, 9000, 200, 1), ("mips", 128, 100, 9000, 33, 4),
     ("l2", 64, 100, 6000, 70, None), ("l2", 100, 50, 6000, 70, None), ("l2", 32, 100, 700, 20, 5),
     ("l2", 128, 100, 50, 10, None), ("l2", 128, 100, 64, 64, 1), ("mips", 96, 30, 129, 3, 2),
+    ("l2", 128, 112, 5000, 65, 3), ("l2", 128, 113, 5000, 65, 2), ("mips", 128, 112, 3000, 17, None),      # 7 / 8 list registers per row
 ])
 def test_bruteforce_register_list_kernel(oracle, metric, d, k, n, nq, nsplit):
     """two-byte floats, rows <= 256 bytes, k in 17..128: dense_gt_mfma_kernel (lists in registers, B double-buffered);
