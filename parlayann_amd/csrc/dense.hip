@@ -670,7 +670,10 @@ __global__ void __launch_bounds__(256) dense_topk_mfma_f16_kernel(DenseArgs A) {
 constexpr int GT_BSTRIDE = DT_SEG;
 constexpr int GT_BT_BYTES = DT_B * GT_BSTRIDE;
 __device__ __forceinline__ uint32_t gt_swz(uint32_t row, uint32_t off) { return row * GT_BSTRIDE + (off ^ ((row & 15u) << 4)); }
-constexpr uint32_t GT_TAU_PERIOD = 8;      // tiles between two looks at what the other pieces of a row have published
+#ifndef PANN_GT_TAU_PERIOD
+#define PANN_GT_TAU_PERIOD 16
+#endif
+constexpr uint32_t GT_TAU_PERIOD = PANN_GT_TAU_PERIOD;      // tiles between two looks at what the other pieces of a row have published (4 / 8 / 16 / 32: see DESIGN.md K4c)
 
 // |row|^2 of every point, summed like the staging code of the kernel above (16 lanes x 16 bytes, f32 fma chain per lane,
 // butterfly over the 16 lanes)
@@ -748,15 +751,32 @@ __device__ __forceinline__ void gt_sel_init(GtSel<NR>& S, uint32_t m, uint32_t r
 // (the pieces together hold at least m keys at or below it), so it is a valid threshold for every piece -- and much tighter
 // than a piece's own m-th best, which has seen only 1/nsplit of the points.  A stale or missing value only lets more
 // candidates through.
+// max over the 16 lanes of a quarter, in every lane (the butterfly of group_sum)
+__device__ __forceinline__ uint32_t gt_quarter_max(uint32_t v) {
+  v = max(v, (uint32_t)dpp_mov<0xB1>((int)v));     // lane ^ 1
+  v = max(v, (uint32_t)dpp_mov<0x4E>((int)v));     // lane ^ 2
+  v = max(v, (uint32_t)dpp_mov<0x141>((int)v));    // row_half_mirror
+  v = max(v, (uint32_t)dpp_mov<0x140>((int)v));    // row_mirror
+  return v;
+}
+// (Lane l of a quarter reads piece l, l + 16, ... of the quarter's row 4q + r: the loads of the four row sets are issued together
+//  and waited for once, then a butterfly takes the maximum.  One lane reading piece after piece in a loop -- a dependent,
+//  individually awaited sc1 load per piece and row -- made a refresh every 8 tiles cost 0.4 ms of 8.1 at 10K x 1M, k = 100.)
 template <int NR>
-__device__ __forceinline__ void gt_sel_refresh(GtSel<NR>& S, const uint32_t* gtau_rows, uint32_t row0, uint32_t na_tile, uint32_t nsplit) {
+__device__ __forceinline__ void gt_sel_refresh(GtSel<NR>& S, const uint32_t* gtau_rows, uint32_t row0, uint32_t na_tile, uint32_t nsplit, int lane) {
+  uint32_t g[4] = {0u, 0u, 0u, 0u};
+  for (uint32_t c0 = 0; c0 < nsplit; c0 += 16) {
+    const uint32_t cpiece = c0 + (uint32_t)(lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const uint32_t* gp = gtau_rows + (size_t)min(row0 + r, na_tile - 1u) * nsplit;
+      if (cpiece < nsplit) g[r] = max(g[r], __hip_atomic_load(gp + cpiece, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+  }
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    const uint32_t* gp = gtau_rows + (size_t)min(row0 + r, na_tile - 1u) * nsplit;
-    uint32_t g = 0;
-    for (uint32_t cpiece = 0; cpiece < nsplit; cpiece++)
-      g = max(g, __hip_atomic_load(gp + cpiece, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    const float gf = g == 0xFFFFFFFFu ? __builtin_inff() : ord2f(g);
+    const uint32_t gm = gt_quarter_max(g[r]);
+    const float gf = gm == 0xFFFFFFFFu ? __builtin_inff() : ord2f(gm);
     S.tauf[r] = S.rowok[r] ? fminf(S.tauf[r], gf) : S.tauf[r];
   }
 }
@@ -1083,7 +1103,7 @@ __global__ void __launch_bounds__(256, PANN_GT_WGS) dense_gt_mfma_kernel(DenseAr
     const uint64_t bt = bs + (uint64_t)i * DT_B;
     if (A.nsplit > 1 && --tau_wait == 0) {
       tau_wait = tau_period;
-      gt_sel_refresh<NR>(S, gtau + a0 * A.nsplit, (uint32_t)(wave * DT_AW + q * 4), na_tile, A.nsplit);
+      gt_sel_refresh<NR>(S, gtau + a0 * A.nsplit, (uint32_t)(wave * DT_AW + q * 4), na_tile, A.nsplit, lane);
     }
     // No branches around these: beyond the last tile they re-stage the piece's last row (clamped loads, SENTINEL labels)
     // into the buffer nobody reads again -- with conditional staging the compiler waited for the requests just made
@@ -1327,7 +1347,7 @@ __global__ void __launch_bounds__(256, 2) dense_gt_valu_kernel(DenseArgs A, cons
   for (uint32_t u = 0; u < nunits; u++) {
     const int buf = (int)(u & 1);
     const uint32_t sg = nseg == 2 ? (u & 1) : 0u;
-    if (sg == 0 && A.nsplit > 1 && --tau_wait == 0) { tau_wait = tau_period; gt_sel_refresh<NR>(S, gtau + a0 * A.nsplit, (uint32_t)(wave * DT_AW + q * 4), na_tile, A.nsplit); }
+    if (sg == 0 && A.nsplit > 1 && --tau_wait == 0) { tau_wait = tau_period; gt_sel_refresh<NR>(S, gtau + a0 * A.nsplit, (uint32_t)(wave * DT_AW + q * 4), na_tile, A.nsplit, lane); }
     store_pre(u + 1);                                          // (beyond the last step: the piece's last row again, into a dead buffer)
     load_pre(u + 2);
     if (sg == 0) {
