@@ -930,6 +930,10 @@ __device__ __forceinline__ void gt_select_queued(GtSel<NR>& S, const float (&d)[
   }
   if ((rowm[0] | rowm[1] | rowm[2] | rowm[3]) == 0ull) return;
   GT_COUNT(1, 1);                                                // wave-tiles with a survivor of the float test
+  // from here on this wave keeps its three siblings at the tile barrier: it goes ahead of the other workgroup's wave on its SIMD
+  // (7.45 -> 7.3 ms at 10K x 1M, k = 100)
+  __builtin_amdgcn_s_setprio(3);
+  struct PrioReset { __device__ ~PrioReset() { __builtin_amdgcn_s_setprio(0); } } prio_reset;
   const uint32_t below = (1u << (lane & 15)) - 1u;
   uint32_t left = 0;                                             // wave-uniform: bit 4r + t
 #pragma unroll
